@@ -1,0 +1,261 @@
+"""Pin the oracle (oracle/ref_torch.py) against the REAL reference and emit golden
+fixtures under tests/golden/.  Runs only in the build container, where
+/root/reference exists; nothing here travels to the GPU box except the small .pt
+fixtures it writes.  The reference is imported on CPU with stub modules for the
+third-party packages that are absent (timm, cv2, torchvision, seaborn, numba) --
+the recipe recorded in SURVEY.md section 8(c).
+
+usage: python oracle/gen_golden.py [--skip-full]
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import os
+import sys
+import types
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import ref_torch as R  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class DropPath(torch.nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+    stub("timm")
+    stub("timm.models")
+    stub("timm.models.layers", DropPath=DropPath, to_2tuple=lambda x: (x, x) if not isinstance(x, tuple) else x,
+         trunc_normal_=torch.nn.init.trunc_normal_)
+    stub("cv2", setNumThreads=lambda n: None, ocl=types.SimpleNamespace(setUseOpenCL=lambda b: None))
+    tv = stub("torchvision")
+    tv.ops = stub("torchvision.ops")
+    tv.transforms = stub("torchvision.transforms")
+    tv.models = stub("torchvision.models")
+    stub("seaborn")
+    stub("numba", jit=lambda *a, **k: (lambda f: f))
+    if "/root" not in sys.path:
+        sys.path.insert(0, "/root")
+    return importlib.import_module("reference.basics.models.model"), \
+        importlib.import_module("reference.basics.models.backbone_vit"), \
+        importlib.import_module("reference.basics.models.common")
+
+
+def load_into(module: torch.nn.Module, sd, prefix=""):
+    own = module.state_dict()
+    for k, v in own.items():
+        if v.dtype.is_floating_point and (prefix + k) in sd:
+            v.copy_(sd[prefix + k].to(v.dtype))
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+def sub(t, step):
+    return t[..., ::step, ::step].contiguous() if t.dim() == 4 else t
+
+
+def tiny_sd(mod: torch.nn.Module, seed: int):
+    """Fill a tiny reference module with closed-form values and return its float state."""
+    out = {}
+    with torch.no_grad():
+        for k, v in mod.state_dict().items():
+            if not v.dtype.is_floating_point:
+                continue
+            if k.endswith("attn_mask"):
+                continue
+            u = R._hash01(f"{seed}:{k}", v.numel()).view(v.shape).to(v.dtype)
+            if k.endswith("running_var"):
+                val = 1.0 + 0.25 * u
+            elif ("norm" in k or "bn" in k) and k.endswith("weight"):
+                val = 1.0 + 0.2 * u
+            elif v.dim() >= 2:
+                fan = v[0].numel()
+                val = u * (1.5 / fan ** 0.5)
+            else:
+                val = 0.2 * u
+            v.copy_(val)
+            out[k] = val.clone()
+    return out
+
+
+def per_module_goldens(ref_vit, ref_common, out):
+    """Tiny instantiations of the reference's own classes (KB-sized fixtures)."""
+    torch.manual_seed(0)
+    g = {}
+    # ---- SwinTransformerBlock: (shift 0, linear), (shift 2, conv), window-clamped
+    for tag, kw, (H, W) in (
+        ("swin_lin", dict(dim=24, num_heads=12, window_size=8, shift_size=0, linear_mlp=True), (16, 16)),
+        ("swin_conv", dict(dim=24, num_heads=12, window_size=8, shift_size=2, linear_mlp=False), (16, 24)),
+        ("swin_clamp", dict(dim=24, num_heads=12, window_size=32, shift_size=0, linear_mlp=True), (8, 8)),
+    ):
+        blk = ref_vit.SwinTransformerBlock(input_resolution=(H, W), **kw)
+        sd = tiny_sd(blk, 1)
+        x = R._hash01(tag, 2 * H * W * 24).view(2, H * W, 24).float().requires_grad_(True)
+        y = blk(x)
+        (y * R._hash01(tag + "g", y.numel()).view(y.shape).float()).sum().backward()
+        grads = {k: p.grad.clone() for k, p in blk.named_parameters()}
+        # oracle check
+        osd = {"b." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xo = x.detach().clone().requires_grad_(True)
+        yo = R.swin_block(osd, "b.", xo, H, W, kw["window_size"], kw["shift_size"], kw["linear_mlp"])
+        (yo * R._hash01(tag + "g", y.numel()).view(y.shape).float()).sum().backward()
+        d = maxdiff(y, yo)
+        dg = max(maxdiff(grads[k], osd["b." + k].grad) for k in grads)
+        dx = maxdiff(x.grad, xo.grad)
+        print(f"[pin] {tag}: fwd {d:.2e} dparam {dg:.2e} dx {dx:.2e}")
+        assert d < 1e-5 and dg < 1e-4 and dx < 1e-5, tag
+        g[tag] = dict(cfg=dict(H=H, W=W, **kw), sd=sd, x=x.detach(), y=y.detach(), dx=x.grad.clone(), grads=grads)
+    # ---- PatchMerging
+    pm = ref_vit.PatchMerging((8, 12), 16)
+    sd = tiny_sd(pm, 2)
+    x = R._hash01("pm", 2 * 96 * 16).view(2, 96, 16).float()
+    y = pm(x, (8, 12))
+    yo = R.patch_merging({"p." + k: v for k, v in sd.items()}, "p.", x, 8, 12)
+    print(f"[pin] patch_merging {maxdiff(y, yo):.2e}")
+    assert maxdiff(y, yo) < 1e-5
+    g["pmerge"] = dict(sd=sd, x=x, y=y.detach(), H=8, W=12)
+    # ---- CAttentionBlock at window 1 (shipped) and general (window 2, shift 0 / 1)
+    for tag, ws, shift in (("ca_w1", 1, 0), ("ca_w2", 2, 0), ("ca_w2s1", 2, 1)):
+        blk = ref_vit.CAttentionBlock(embedding_dim=48, num_heads=12, shift_size=shift)
+        blk.window_size = ws
+        blk.input_resolution = (8, 8)
+        if shift > 0:   # rebuild the mask for the overridden window / resolution (ctor lines :441-459)
+            blk.attn_mask = R.shift_mask(8, 8, ws, shift)
+        sd = tiny_sd(blk, 3)
+        ins = [R._hash01(tag + str(i), 2 * 64 * 48).view(2, 8, 8, 48).float() for i in range(4)]
+        outs = blk(*ins)
+        oo = R.cattention_block({"c." + k: v for k, v in sd.items()}, *ins, window_size=ws, shift=shift, pfx="c.")
+        d = max(maxdiff(a, b) for a, b in zip(outs, oo))
+        print(f"[pin] {tag} {d:.2e}")
+        assert d < 1e-5
+        g[tag] = dict(sd=sd, ins=ins, outs=[o.detach() for o in outs], ws=ws, shift=shift)
+    # ---- PatchEmbed pad 1 vs 0
+    for tag, pad in (("pe_pad1", (1, 1)), ("pe_pad0", (0, 0))):
+        pe = ref_vit.PatchEmbed(kernel_size=(4, 4), stride=(4, 4), padding=pad, in_chans=1, embed_dim=48)
+        sd = tiny_sd(pe, 4)
+        x = R._hash01(tag, 2 * 32 * 32).view(2, 1, 32, 32).float()
+        g[tag] = dict(sd=sd, x=x, y=pe(x).detach())
+    # ---- Conv / C3 train (batch-stat BN) + eval
+    for tag, mk in (("conv1", lambda: ref_common.Conv(16, 24, 1)), ("conv3", lambda: ref_common.Conv(16, 24, 3)),
+                    ("c3", lambda: ref_common.C3(24, 16, 1, False))):
+        m = mk()
+        for mm in m.modules():
+            if isinstance(mm, torch.nn.BatchNorm2d):
+                mm.eps, mm.momentum = R.BN_EPS, R.BN_MOMENTUM
+        sd = tiny_sd(m, 5)
+        cin = 16 if tag != "c3" else 24
+        x = R._hash01(tag, 2 * cin * 8 * 12).view(2, cin, 8, 12).float().requires_grad_(True)
+        m.train()
+        y = m(x)
+        (y * R._hash01(tag + "g", y.numel()).view(y.shape).float()).sum().backward()
+        grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+        after = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+        ns = {}
+        osd = {"m." + k: v for k, v in sd.items()}
+        yo = R.conv_bn_silu(osd, "m.", x.detach(), True, ns) if tag != "c3" else R.c3(osd, "m.", x.detach(), True, ns)
+        d = maxdiff(y, yo)
+        ds = max(maxdiff(after[k], ns["m." + k]) for k in after)
+        m.eval()
+        ye = m(x.detach())
+        osd2 = dict(osd)
+        osd2.update(ns)
+        yeo = R.conv_bn_silu(osd2, "m.", x.detach(), False, None) if tag != "c3" else R.c3(osd2, "m.", x.detach(), False, None)
+        print(f"[pin] {tag}: train {d:.2e} stats {ds:.2e} eval {maxdiff(ye, yeo):.2e}")
+        assert d < 1e-5 and ds < 1e-6 and maxdiff(ye, yeo) < 1e-5
+        g[tag] = dict(sd=sd, x=x.detach(), y=y.detach(), dx=x.grad.clone(), grads=grads, stats_after=after, y_eval=ye.detach())
+    torch.save(g, os.path.join(out, "per_module.pt"))
+
+
+def full_model_goldens(ref_model, out):
+    """Whole model @512^2 with procedural weights."""
+    Model = ref_model.Model
+    torch.manual_seed(0)
+    m = Model("/root/reference/models/model.yaml", input_mode="RGB+IR", ch_steam=3, ch=128, nc=8)
+    sd = R.procedural_state_dict(512, 8)
+    keys_ref = {k for k, v in m.state_dict().items() if v.dtype.is_floating_point and not k.endswith("attn_mask")}
+    assert keys_ref == set(sd.keys()), (sorted(keys_ref - set(sd))[:5], sorted(set(sd) - keys_ref)[:5])
+    nparams = sum(p.numel() for p in m.parameters())
+    assert nparams == 22007851, nparams
+    with torch.no_grad():
+        load_into(m, sd)
+    x_rgb, x_ir = R.synthetic_inputs(1, 512, seed=0)
+    m.train()
+    pred, feats = m(x_rgb, x_ir, "RGB+IR")
+    loss = pred[0].float().square().mean()
+    loss.backward()
+    gnorm = {k: float(p.grad.double().norm()) for k, p in m.named_parameters()}
+    stats_after = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}
+
+    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "anchor" not in k)
+           for k, v in sd.items()}
+    ns, taps = {}, {}
+    opred, ofeats = R.model_forward(osd, x_rgb, x_ir, True, ns, taps)
+    oloss = opred[0].square().mean()
+    oloss.backward()
+    d = maxdiff(pred[0], opred[0])
+    print(f"[pin] full model train logits maxdiff {d:.3e} (|logit| max {float(pred[0].abs().max()):.2f})")
+    assert d < 1e-4
+    for i in range(3):
+        di = maxdiff(feats[i], ofeats[i])
+        print(f"[pin] encoder out {i}: {di:.3e}")
+        assert di < 1e-4
+    # stage3.0.mlp.fc2.bias has a mathematically zero gradient (a per-channel constant in
+    # front of a bias-free 1x1 conv followed by batch-stat BN), so compare with an absolute floor.
+    dgn = max((abs(gnorm[k] - float(osd[k].grad.double().norm())) - 1e-7) / (gnorm[k] + 1e-12) for k in gnorm)
+    print(f"[pin] grad-norm rel diff max {dgn:.3e} (after 1e-7 abs floor)")
+    assert dgn < 1e-4
+    dst = max(maxdiff(stats_after[k], ns[k]) for k in stats_after)
+    print(f"[pin] BN running stats {dst:.2e}")
+    assert dst < 1e-5
+    m.eval()
+    with torch.no_grad():
+        z, praw, _ = m(x_rgb, x_ir, "RGB+IR")
+        osd2 = {k: v.detach() for k, v in osd.items()}
+        osd2.update(ns)
+        oz, opraw, _ = R.model_forward(osd2, x_rgb, x_ir, False)
+    print(f"[pin] eval decode maxdiff {maxdiff(z, oz):.3e}")
+    assert maxdiff(z, oz) < 1e-3
+    gold = dict(
+        img_size=512, B=1, seed=0,
+        logits_sub=pred[0].detach()[:, :, ::8, ::8, :].contiguous(),
+        feats_sub=[sub(f.detach(), 8) for f in feats[:3]],
+        taps_sub={k: v.detach().view(1, -1, v.shape[-1])[:, ::97, ::7].contiguous() for k, v in taps.items()},
+        loss=float(loss), gnorm=gnorm,
+        stats_after_sub={k: v[::8].clone() for k, v in stats_after.items()},
+        z_sub=z[:, ::257, :].contiguous(),
+    )
+    torch.save(gold, os.path.join(out, "full_model_512.pt"))
+    print("[pin] wrote full_model_512.pt")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-full", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 8)
+    ref_model, ref_vit, ref_common = import_reference()
+    per_module_goldens(ref_vit, ref_common, GOLD)
+    if not a.skip_full:
+        full_model_goldens(ref_model, GOLD)
+
+
+if __name__ == "__main__":
+    main()
