@@ -1,0 +1,191 @@
+/* C ABI of libsodt_hip.so -- the MI355X (gfx950) kernels beneath the reference's
+ * Python nn.Module boundary (Model / ImageEncoderViT / C3 / Detect).
+ *
+ * The reference (Bissmella/Small-object-detection-transformers) has no FFI: every op
+ * on its hot path is a torch.nn call.  Each entry point below therefore cites the
+ * reference lines whose ATen op sequence it replaces (paths relative to the
+ * reference root).  Conventions: raw device pointers + explicit sizes, caller-owned
+ * memory (workspaces included), a hipStream_t argument, int return (0 = ok,
+ * SODT_EINVAL = shape/alignment the kernel does not support -- nothing launched),
+ * no allocation / synchronisation / exceptions inside; safe to capture in a hipGraph.
+ *
+ * dtype: 0 = float32 (parity path, exact-f32 MFMA), 1 = bfloat16 (throughput path,
+ * f32 accumulate).  Activations are token-major ("NHWC"): row = (b*H + y)*W + x,
+ * channels contiguous.  Parameters handed to the kernels are the "prepared" copies
+ * produced by sodt_prep_weights (cast to the run dtype, GEMM layouts [N][K]).
+ */
+#ifndef SODT_HIP_H
+#define SODT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* sodt_stream_t;   /* == hipStream_t */
+
+#define SODT_F32 0
+#define SODT_BF16 1
+#define SODT_MAX_SEG 9
+
+/* One K-segment of a GEMM's left operand: a (possibly spatially mapped) view of a
+ * token-major tensor.  For output row m = (b, y, x) on the (Ho, Wo) grid the source
+ * pixel is ((y*mul + dy) >> shr, (x*mul + dx) >> shr) on the (Hi, Wi) grid; rows
+ * that fall outside read as zeros.  This one mechanism expresses the 2x2 conv of the
+ * enhanced Swin MLP (backbone_vit.py:892-905), the 3x3 Bottleneck conv
+ * (common.py:61), PatchMerging's 2x2 gather (backbone_vit.py:848-855),
+ * nn.Upsample(x2, nearest) + Concat (models/model.yaml:66-72), channel concat of the
+ * necks (backbone_vit.py:239,268) and every transposed (backward) form of them. */
+typedef struct {
+  const void* p;   /* base pointer, already offset to the first channel used */
+  int ld;          /* row stride in elements */
+  int klen;        /* channels taken from this segment (multiple of 16 bytes) */
+  int dy, dx;      /* tap offset */
+  int mul, shr;    /* stride multiply / upsample shift */
+  int Hi, Wi;      /* source grid */
+} sodt_seg;
+
+typedef struct {
+  sodt_seg s[SODT_MAX_SEG];
+  int nseg;
+  int spatial;     /* 0: source row == output row for every segment */
+  int Ho, Wo;      /* output grid (rows = B*Ho*Wo) when spatial */
+} sodt_aspec;
+
+/* epilogue flags of sodt_gemm_nt */
+#define SODT_EPI_BIAS 1          /* + bias[n] (f32) */
+#define SODT_EPI_RESID 2         /* + R[m % rmod or m][n] */
+#define SODT_EPI_GELU_DUAL 4     /* C = pre-activation, C2 = GELU(erf) of it */
+#define SODT_EPI_DGELU 8         /* value *= gelu'(aux[m][n]) */
+#define SODT_EPI_STATS 16        /* stats[0][n] += sum_m v, stats[1][n] += sum_m v*v (f64 atomics) */
+#define SODT_EPI_AFFINE_SILU 32  /* v = silu(v*scale[n] + shift[n])  (fused / eval-mode Conv) */
+#define SODT_EPI_DETECT 64       /* store f32 to (B, na, HW, no): Detect's view+permute */
+#define SODT_EPI_OUT_F32 128     /* C is float regardless of dtype */
+
+typedef struct {
+  sodt_aspec a;                 /* A [M][K] as K-segments */
+  const void* W; int ldw;       /* W [N][K], run dtype */
+  void* C; int ldc;
+  void* C2; int ldc2;
+  const float* bias;
+  const void* R; int ldr; int rmod;
+  const void* aux; int ldaux;
+  double* stats;                /* [2][N] */
+  const float* scale; const float* shift;
+  int M, N, K, flags;
+  int oscatter, omul, ody, odx, OH, OW;   /* optional output-row scatter (PatchMerging backward) */
+  int det_na, det_no, det_hw;
+} sodt_gemm_args;
+
+/* C = epilogue(A @ W^T): every nn.Linear / 1x1 / 2x2 / 3x3 Conv2d forward and every
+ * input-gradient GEMM of the path (backbone_vit.py:968,990,886-904,857,213,268-270;
+ * common.py:43,49; model.py:53). */
+int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st);
+
+typedef struct {
+  const void* dY; int ldy;      /* [M][N] run dtype */
+  sodt_aspec x;                 /* X [M][K] as K-segments (same row mapping as the forward A) */
+  float* dW; int lddw;          /* [N][K] f32, accumulated with atomics (zero it first) */
+  float* dbias;                 /* [N] f32 or NULL: += column sums of dY */
+  int M, N, K;
+  int kperm_c, kperm_t;         /* if kperm_t > 1: column k = tap*C + ci is stored at ci*T + tap (torch conv layout) */
+  int splits;                   /* M is cut into this many slices (grid.y) */
+} sodt_gemm_tn_args;
+
+/* dW += dY^T @ X (+ dbias): every weight gradient of the path (autograd of the
+ * reference ops listed above). */
+int sodt_gemm_tn(const sodt_gemm_tn_args* g, int dtype, sodt_stream_t st);
+
+/* LayerNorm over the last dim, eps 1e-5 (backbone_vit.py:1090,1128,858).  y and stats
+ * (mean, rstd per row, f32 [M][2]) are written; C % (16 bytes) == 0. */
+int sodt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                       int M, int C, int dtype, sodt_stream_t st);
+/* dx = [dres +] LN'(dy); dgamma/dbeta (f32) accumulated with atomics. */
+int sodt_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma,
+                       const void* dres, void* dx, float* dgamma, float* dbeta,
+                       int M, int C, int dtype, sodt_stream_t st);
+
+/* Window multi-head self-attention core on a natural-order QKV tensor
+ * (backbone_vit.py:968-989 + :1094-1124): cyclic shift, window partition, q*scale@k^T,
+ * relative-position bias, -100 shift mask, softmax, @v, un-partition, un-shift are all
+ * index arithmetic inside the kernel.  qkv [B*H*W][3C], out [B*H*W][C], lse f32
+ * [B*H*W][heads], bias_t f32 [heads][(2ws-1)^2] (transposed table). */
+int sodt_window_attn_fwd(const void* qkv, const float* bias_t, void* out, float* lse,
+                         int B, int H, int W, int C, int heads, int ws, int shift,
+                         int dtype, sodt_stream_t st);
+/* dqkv from dout (recomputes P); dbias_t accumulated with atomics; dq_acc is an f32
+ * [B*H*W][C] scratch needed (and zeroed by the caller) only when ws*ws > 64. */
+int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const void* out, const void* dout,
+                         const float* lse, void* dqkv, float* dbias_t, float* dq_acc,
+                         int B, int H, int W, int C, int heads, int ws, int shift,
+                         int dtype, sodt_stream_t st);
+
+/* Front end (backbone_vit.py:195-210): channel split, 4x Conv2d(1->48,k4,s4) (R with
+ * padding 1), pairwise cross-channel attention (R<-G, G<-B, B<-IR, IR<-G; 12 heads x 4,
+ * scale 1/2, window ca_ws, no projections) + residual + LayerNorm(48), concatenated to
+ * [B*t*t][192].  rgb (B,3,S,S) f32 / ir plane pointer with its batch stride, f32 in
+ * [0,1].  params f32: w[4][48][16], b[4][48], gamma[4][48], beta[4][48].  ca_ws == 1
+ * is the shipped configuration (backbone_vit.py:438). */
+int sodt_frontend_fwd(const float* rgb, const float* ir, long ir_bstride, const float* w, const float* b,
+                      const float* gamma, const float* beta, void* out, int B, int S, int ca_ws,
+                      int dtype, sodt_stream_t st);
+int sodt_frontend_bwd(const float* rgb, const float* ir, long ir_bstride, const float* w, const float* b,
+                      const float* gamma, const float* beta, const void* dout,
+                      float* dw, float* db, float* dgamma, float* dbeta, int B, int S, int ca_ws,
+                      int dtype, sodt_stream_t st);
+
+/* BatchNorm2d (eps 1e-3, momentum 0.03) + SiLU of the head's Conv (common.py:38-50,
+ * torch_utils.py:150-152), token-major.  stats f64 [2][C] from SODT_EPI_STATS.
+ * finalize: mean/rstd (f32 [2][C]) + running-stat update (unbiased var); stats == NULL
+ * takes mean/rstd from the running statistics (eval). */
+int sodt_bn_finalize(const double* stats, float* mean_rstd, float* running_mean, float* running_var,
+                     long count, int C, float eps, float momentum, sodt_stream_t st);
+/* scale = gamma*rstd, shift = beta - mean*scale: the fused / eval-mode form (torch_utils.py:182-203) */
+int sodt_bn_affine(const float* mean_rstd, const float* gamma, const float* beta, float* scale, float* shift,
+                   int C, sodt_stream_t st);
+int sodt_bn_silu_fwd(const void* z, const float* mean_rstd, const float* gamma, const float* beta,
+                     void* y, int ldy, long M, int C, int dtype, sodt_stream_t st);
+/* pass 1: red[0][c] += sum g, red[1][c] += sum g*xhat with g = dy * silu'(a);  pass 2: dz */
+int sodt_bn_silu_bwd_reduce(const void* dy, int lddy, const void* z, const float* mean_rstd,
+                            const float* gamma, const float* beta, double* red, long M, int C,
+                            int dtype, sodt_stream_t st);
+int sodt_bn_silu_bwd_apply(const void* dy, int lddy, const void* z, const float* mean_rstd,
+                           const float* gamma, const float* beta, const double* red, void* dz,
+                           float* dgamma, float* dbeta, long M, int C, int dtype, sodt_stream_t st);
+
+/* dst[(b,y,x)][coff : coff+C] = src[(b, y>>shr, x>>shr)][0:C]  (nn.Upsample nearest + Concat slot) */
+int sodt_copy_rows(const void* src, int lds_, void* dst, int ldd, int B, int Ho, int Wo, int shr, int C,
+                   int dtype, sodt_stream_t st);
+/* dsrc[(b,y,x)][c] (+)= sum_{a,b<2^shr} d[(b, (y<<shr)+a, (x<<shr)+b)][c]  (their backward) */
+int sodt_gather_sum_rows(const void* d, int ldd, void* dsrc, int lds_, int B, int Hs, int Ws, int shr, int C,
+                         int accumulate, int dtype, sodt_stream_t st);
+
+/* Detect: dpred f32 (B, na, HW, no) -> dz run dtype [B*HW][ldz] (cols >= na*no zeroed)  (model.py:55 backward) */
+int sodt_detect_unpermute(const float* dpred, void* dz, int ldz, int B, int HW, int na, int no,
+                          int dtype, sodt_stream_t st);
+/* Detect eval decode (model.py:61-64): raw f32 (B,na,ny,nx,no) -> z f32 (B, na*ny*nx, no) */
+int sodt_detect_decode(const float* raw, const float* anchor_grid, float* z, int B, int na, int ny, int nx,
+                       int no, float stride, sodt_stream_t st);
+
+/* Batched parameter preparation: out = cast(permute3(in)) for a device-resident table. */
+typedef struct {
+  const float* src; void* dst;
+  int d0, d1, d2;       /* source viewed as [d0][d1][d2] */
+  int p0, p1, p2;       /* destination dims order: dst[i_p0][i_p1][i_p2] */
+  int dst_ld;           /* elements per destination "row" (>= product of the trailing two dims) */
+  int pad_;
+} sodt_prep_desc;
+int sodt_prep_weights(const sodt_prep_desc* table_dev, int n, int max_elems, int dtype, sodt_stream_t st);
+
+/* bias table (L, heads) f32 -> (heads, L) f32, and the reverse accumulate for its gradient */
+int sodt_transpose_f32(const float* src, float* dst, int rows, int cols, int accumulate, sodt_stream_t st);
+
+/* f32 <-> run dtype elementwise cast */
+int sodt_cast(const void* src, void* dst, long n, int src_dtype, int dst_dtype, sodt_stream_t st);
+
+const char* sodt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,630 @@
+// Window multi-head self-attention core (W-MSA / SW-MSA) for gfx950.
+//
+// Replaces, for one Swin block, the reference's roll -> window_partition -> per-head
+// split -> q*scale @ k^T -> + relative_position_bias_table[index] -> + attn_mask(0/-100)
+// -> softmax -> @ v -> head merge -> window_unpartition -> roll back
+// (backbone_vit.py:1094-1124, :968-989).  The QKV tensor stays in natural token order
+// [B*H*W][3C]; shift, partition, mask region and relative index are index arithmetic.
+// The N x N score matrix is never written to memory.
+//
+// One workgroup = NW waves = NW heads of one (window, 64-query tile); keys/values are
+// walked in 64-key tiles with an online softmax (one tile when the window is 8x8,
+// sixteen when it is 32x32).  Q K^T and P V run on MFMA 16x16 tiles through the
+// dtype-generic mma16<T>() of common.h; P goes through LDS to become an A operand and
+// V is transposed while it is staged so that both MFMA operands are k-contiguous.
+//
+// Backward recomputes P from the saved log-sum-exp (flash style): per (q tile, kv
+// tile) it forms S, dP = dO V^T, dS = P o (dP - delta), then dV += P^T dO,
+// dK += dS^T Q, dQ += dS K.  The relative-position-bias gradient is accumulated in a
+// small LDS table per head ((2R-1) x (2ws-1) <= 225 entries, R = 64/ws rows per tile)
+// and flushed with a few global atomics.
+#include "common.h"
+#include "../../include/sodt_hip.h"
+
+namespace {
+
+struct AttnGeo {
+  int B, H, W, C, heads, ws, shift;
+  int nwy, nwx, N, nqt;   // windows per column/row, tokens per window, 64-token tiles per window
+};
+
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
+// token row + mask region of window-local token n of window (b, wy, wx)
+__device__ __forceinline__ void win_token(const AttnGeo& g, int b, int wy, int wx, int n, int& row, int& rid,
+                                          int& iy, int& ix) {
+  iy = n / g.ws; ix = n - iy * g.ws;
+  const int ys = wy * g.ws + iy, xs = wx * g.ws + ix;
+  int y = ys + g.shift, x = xs + g.shift;
+  if (y >= g.H) y -= g.H;
+  if (x >= g.W) x -= g.W;
+  row = (b * g.H + y) * g.W + x;
+  rid = 0;
+  if (g.shift > 0) {
+    const int ry = ys < g.H - g.ws ? 0 : (ys < g.H - g.shift ? 1 : 2);
+    const int rx = xs < g.W - g.ws ? 0 : (xs < g.W - g.shift ? 1 : 2);
+    rid = ry * 3 + rx;
+  }
+}
+
+template <typename T, int HD>
+struct Lay {
+  static constexpr int E = TT<T>::SZ;
+  static constexpr int KPL = TT<T>::KPL;
+  static constexpr int QROW = HD * E + 16;     // [64 tokens][HD] tile row (bytes)
+  static constexpr int TROW = 64 * E + 16;     // [HD][64 tokens] and [64][64] tile row (bytes)
+  static constexpr int QTILE = 64 * QROW;
+  static constexpr int TTILE = HD * TROW;
+  static constexpr int STILE = 64 * TROW;
+  static constexpr int DCH = HD / KPL;         // 16-byte chunks per head row
+  static constexpr int KBQ = (HD + TT<T>::MMA_K - 1) / TT<T>::MMA_K;   // mma steps over d
+  static constexpr int KBT = 64 / TT<T>::MMA_K;                        // mma steps over 64 tokens
+};
+
+// MFMA operand fragment from a [rows][K] tile: lane reads 16 bytes at (row0 + (l&15), k = kb*MMA_K + KPL*(l>>4))
+template <typename T>
+__device__ __forceinline__ uint4 frag(const unsigned char* tile, int rowbytes, int row0, int kb, int klimit, int lane) {
+  const int k = kb * TT<T>::MMA_K + TT<T>::KPL * (lane >> 4);
+  if (k >= klimit) return make_uint4(0, 0, 0, 0);
+  return *(const uint4*)(tile + (row0 + (lane & 15)) * rowbytes + k * TT<T>::SZ);
+}
+
+template <typename T> __device__ __forceinline__ void st_elem(unsigned char* p, float v) { *(T*)p = from_f<T>(v); }
+
+// store 4 consecutive elements (accumulator rows 4g..4g+3 of one column) into a transposed tile
+template <typename T> __device__ __forceinline__ void st4(unsigned char* p, const f32x4& v);
+template <> __device__ __forceinline__ void st4<float>(unsigned char* p, const f32x4& v) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16>(unsigned char* p, const f32x4& v) {
+  *(uint2*)p = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+}
+
+// ---------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------
+template <typename T, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
+                                                          T* __restrict__ out, float* __restrict__ lse, const AttnGeo g) {
+  using L = Lay<T, HD>;
+  constexpr int E = L::E, KPL = L::KPL;
+  constexpr int NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE];
+  __shared__ __attribute__((aligned(16))) unsigned char sK[NW * L::QTILE];
+  __shared__ __attribute__((aligned(16))) unsigned char sVT[NW * L::TTILE];
+  __shared__ __attribute__((aligned(16))) unsigned char sP[NW * L::STILE];
+  __shared__ int sTokQ[64], sTokK[64];
+  __shared__ short sGeoQ[64][4], sGeoK[64][4];   // iy, ix, rid, -
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int HG = g.heads / NW;
+  int bid = blockIdx.x;
+  const int hg = bid % HG; bid /= HG;
+  const int qt = bid % g.nqt; bid /= g.nqt;
+  const int wx = bid % g.nwx; bid /= g.nwx;
+  const int wy = bid % g.nwy; const int b = bid / g.nwy;
+  const int head = hg * NW + w;
+  const int C3 = 3 * g.C;
+  const int L2 = 2 * g.ws - 1;
+
+  if (tid < 64) {
+    int row, rid, iy, ix;
+    win_token(g, b, wy, wx, qt * 64 + tid, row, rid, iy, ix);
+    sTokQ[tid] = row; sGeoQ[tid][0] = (short)iy; sGeoQ[tid][1] = (short)ix; sGeoQ[tid][2] = (short)rid;
+  }
+  __syncthreads();
+  // ---- Q tile: 64 rows x NW*HD
+  constexpr int CPR = NW * L::DCH;
+  for (int idx = tid; idx < 64 * CPR; idx += NT) {
+    const int r = idx / CPR, cc = idx - r * CPR;
+    const int h = cc / L::DCH, dc = cc - h * L::DCH;
+    const uint4 v = *(const uint4*)(qkv + (long)sTokQ[r] * C3 + (hg * NW) * HD + cc * KPL);
+    *(uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16) = v;
+  }
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const float scale = rsqrtf((float)HD);
+  float m_run[4][4], l_run[4][4];
+  f32x4 o[4][HD / 16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_run[i][r] = -1e30f; l_run[i][r] = 0.f; }
+#pragma unroll
+    for (int d = 0; d < HD / 16; ++d) o[i][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const unsigned char* myQ = sQ + w * L::QTILE;
+  const unsigned char* myK = sK + w * L::QTILE;
+  const unsigned char* myVT = sVT + w * L::TTILE;
+  unsigned char* myP = sP + w * L::STILE;
+  const float* bt = bias_t + (long)head * L2 * L2;
+
+  for (int kt = 0; kt < g.nqt; ++kt) {
+    if (tid < 64) {
+      int row, rid, iy, ix;
+      win_token(g, b, wy, wx, kt * 64 + tid, row, rid, iy, ix);
+      sTokK[tid] = row; sGeoK[tid][0] = (short)iy; sGeoK[tid][1] = (short)ix; sGeoK[tid][2] = (short)rid;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CPR; idx += NT) {
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int h = cc / L::DCH, dc = cc - h * L::DCH;
+      const T* src = qkv + (long)sTokK[r] * C3 + (hg * NW) * HD + cc * KPL;
+      const uint4 kv = *(const uint4*)(src + g.C);
+      const uint4 vv = *(const uint4*)(src + 2 * g.C);
+      *(uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16) = kv;
+      union { uint4 u; T e[KPL]; } tmp;
+      tmp.u = vv;
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) *(T*)(sVT + h * L::TTILE + (dc * KPL + j) * L::TROW + r * E) = tmp.e[j];
+    }
+    __syncthreads();
+
+    // ---- S = Q K^T (per 16-row strip), bias, mask, online softmax, P -> LDS
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      f32x4 s[4];
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) s[ns] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < L::KBQ; ++kb) {
+        const uint4 fa = frag<T>(myQ, L::QROW, ms * 16, kb, HD, lane);
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) {
+          const uint4 fb = frag<T>(myK, L::QROW, ns * 16, kb, HD, lane);
+          mma16<T>(s[ns], fa, fb);
+        }
+      }
+      int kiy[4], kix[4], krid[4];
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) {
+        kiy[ns] = sGeoK[ns * 16 + fr][0]; kix[ns] = sGeoK[ns * 16 + fr][1]; krid[ns] = sGeoK[ns * 16 + fr][2];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qn = ms * 16 + fg * 4 + r;
+        const int qiy = sGeoQ[qn][0], qix = sGeoQ[qn][1], qrid = sGeoQ[qn][2];
+        float mx = -1e30f;
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) {
+          float v = s[ns][r] * scale + bt[(qiy - kiy[ns] + g.ws - 1) * L2 + (qix - kix[ns] + g.ws - 1)];
+          if (qrid != krid[ns]) v += -100.0f;
+          s[ns][r] = v;
+          mx = fmaxf(mx, v);
+        }
+        mx = group16_max(mx);
+        const float mnew = fmaxf(m_run[ms][r], mx);
+        const float alpha = fast_exp(m_run[ms][r] - mnew);
+        float rs = 0.f;
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) { const float p = fast_exp(s[ns][r] - mnew); s[ns][r] = p; rs += p; }
+        rs = group16_sum(rs);
+        l_run[ms][r] = l_run[ms][r] * alpha + rs;
+        m_run[ms][r] = mnew;
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) o[ms][d][r] *= alpha;
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) st_elem<T>(myP + qn * L::TROW + (ns * 16 + fr) * E, s[ns][r]);
+      }
+    }
+    __syncthreads();
+    // ---- O += P V
+#pragma unroll
+    for (int kb = 0; kb < L::KBT; ++kb) {
+      uint4 fb[HD / 16];
+#pragma unroll
+      for (int d = 0; d < HD / 16; ++d) fb[d] = frag<T>(myVT, L::TROW, d * 16, kb, 64, lane);
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        const uint4 fa = frag<T>(myP, L::TROW, ms * 16, kb, 64, lane);
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) mma16<T>(o[ms][d], fa, fb[d]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- normalise, write lse, stage O through this head's Q tile, coalesced store
+  unsigned char* myO = sQ + w * L::QTILE;
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qn = ms * 16 + fg * 4 + r;
+      const float inv = 1.0f / l_run[ms][r];
+      if (fr == 0 && lse) lse[(long)sTokQ[qn] * g.heads + head] = m_run[ms][r] + __logf(l_run[ms][r]);
+#pragma unroll
+      for (int d = 0; d < HD / 16; ++d) st_elem<T>(myO + qn * L::QROW + (d * 16 + fr) * E, o[ms][d][r] * inv);
+    }
+  __syncthreads();
+  for (int idx = tid; idx < 64 * CPR; idx += NT) {
+    const int r = idx / CPR, cc = idx - r * CPR;
+    const int h = cc / L::DCH, dc = cc - h * L::DCH;
+    *(uint4*)(out + (long)sTokQ[r] * g.C + (hg * NW) * HD + cc * KPL) = *(const uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------
+// delta[tok][head] = sum_d dO * O   (needed only when a window has more than one key tile)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o,
+                                                        float* __restrict__ delta, long M, int C, int heads) {
+  const int hd = C / heads;
+  const long total = M * heads;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long tok = i / heads; const int h = (int)(i - tok * heads);
+    const T* a = o + tok * C + h * hd; const T* bb = d_o + tok * C + h * hd;
+    float s = 0.f;
+    for (int j = 0; j < hd; ++j) s += to_f(a[j]) * to_f(bb[j]);
+    delta[i] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_dq_finish_kernel(const float* __restrict__ acc, T* __restrict__ dqkv,
+                                                            long M, int C) {
+  const long total = M * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long tok = i / C; const int c = (int)(i - tok * C);
+    dqkv[tok * 3 * C + c] = from_f<T>(acc[i]);
+  }
+}
+
+template <typename T, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
+                                                          const T* __restrict__ d_out, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                          float* __restrict__ dbias_t, float* __restrict__ dq_acc,
+                                                          const AttnGeo g, int nwin_total) {
+  using L = Lay<T, HD>;
+  constexpr int E = L::E, KPL = L::KPL;
+  constexpr int NT = NW * 64;
+  constexpr int LTMAX = 225;
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE], sK[NW * L::QTILE], sV[NW * L::QTILE],
+      sDO[NW * L::QTILE];
+  __shared__ __attribute__((aligned(16))) unsigned char sQT[NW * L::TTILE], sKT[NW * L::TTILE], sDOT[NW * L::TTILE];
+  __shared__ __attribute__((aligned(16))) unsigned char sPT[NW * L::STILE], sDS[NW * L::STILE];
+  __shared__ float sDB[NW][LTMAX + 3];
+  __shared__ int sTokQ[64], sTokK[64];
+  __shared__ short sGeoQ[64][4], sGeoK[64][4];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int HG = g.heads / NW;
+  const int hg = blockIdx.y;
+  const int head = hg * NW + w;
+  const int C3 = 3 * g.C;
+  const int L2 = 2 * g.ws - 1;
+  const int R = 64 / g.ws > 0 ? (g.ws >= 64 ? 1 : 64 / g.ws) : 1;   // window rows per 64-token tile
+  const int LT = (2 * R - 1) * L2;
+  const bool single = g.nqt == 1;
+  const float scale = rsqrtf((float)HD);
+  const float* bt = bias_t + (long)head * L2 * L2;
+  constexpr int CPR = NW * L::DCH;
+  (void)HG;
+
+  for (int i = tid; i < NW * (LTMAX + 3); i += NT) (&sDB[0][0])[i] = 0.f;
+
+  unsigned char* myQ = sQ + w * L::QTILE; unsigned char* myK = sK + w * L::QTILE;
+  unsigned char* myV = sV + w * L::QTILE; unsigned char* myDO = sDO + w * L::QTILE;
+  unsigned char* myQT = sQT + w * L::TTILE; unsigned char* myKT = sKT + w * L::TTILE;
+  unsigned char* myDOT = sDOT + w * L::TTILE;
+  unsigned char* myPT = sPT + w * L::STILE; unsigned char* myDS = sDS + w * L::STILE;
+
+  // work items: (window, kv tile); grid-stride so that the LDS bias-gradient table is flushed rarely
+  const int nitems = nwin_total * g.nqt;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    int t = item;
+    const int kt = t % g.nqt; t /= g.nqt;
+    const int wx = t % g.nwx; t /= g.nwx;
+    const int wy = t % g.nwy; const int b = t / g.nwy;
+
+    __syncthreads();
+    if (tid < 64) {
+      int row, rid, iy, ix;
+      win_token(g, b, wy, wx, kt * 64 + tid, row, rid, iy, ix);
+      sTokK[tid] = row; sGeoK[tid][0] = (short)iy; sGeoK[tid][1] = (short)ix; sGeoK[tid][2] = (short)rid;
+    }
+    __syncthreads();
+    // K (+K^T) and V tiles of this kv tile
+    for (int idx = tid; idx < 64 * CPR; idx += NT) {
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int h = cc / L::DCH, dc = cc - h * L::DCH;
+      const T* src = qkv + (long)sTokK[r] * C3 + (hg * NW) * HD + cc * KPL;
+      const uint4 kv = *(const uint4*)(src + g.C);
+      const uint4 vv = *(const uint4*)(src + 2 * g.C);
+      *(uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16) = kv;
+      *(uint4*)(sV + (h * 64 + r) * L::QROW + dc * 16) = vv;
+      union { uint4 u; T e[KPL]; } tmp;
+      tmp.u = kv;
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) *(T*)(sKT + h * L::TTILE + (dc * KPL + j) * L::TROW + r * E) = tmp.e[j];
+    }
+    f32x4 dk[4][HD / 16], dv[4][HD / 16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int d = 0; d < HD / 16; ++d) { dk[i][d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int qt = 0; qt < g.nqt; ++qt) {
+      __syncthreads();
+      if (tid < 64) {
+        int row, rid, iy, ix;
+        win_token(g, b, wy, wx, qt * 64 + tid, row, rid, iy, ix);
+        sTokQ[tid] = row; sGeoQ[tid][0] = (short)iy; sGeoQ[tid][1] = (short)ix; sGeoQ[tid][2] = (short)rid;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 64 * CPR; idx += NT) {
+        const int r = idx / CPR, cc = idx - r * CPR;
+        const int h = cc / L::DCH, dc = cc - h * L::DCH;
+        const uint4 qv = *(const uint4*)(qkv + (long)sTokQ[r] * C3 + (hg * NW) * HD + cc * KPL);
+        const uint4 dv_ = *(const uint4*)(d_out + (long)sTokQ[r] * g.C + (hg * NW) * HD + cc * KPL);
+        *(uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16) = qv;
+        *(uint4*)(sDO + (h * 64 + r) * L::QROW + dc * 16) = dv_;
+        union { uint4 u; T e[KPL]; } t1, t2;
+        t1.u = qv; t2.u = dv_;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+          *(T*)(sQT + h * L::TTILE + (dc * KPL + j) * L::TROW + r * E) = t1.e[j];
+          *(T*)(sDOT + h * L::TTILE + (dc * KPL + j) * L::TROW + r * E) = t2.e[j];
+        }
+      }
+      __syncthreads();
+
+      // ---- phase A: per 16-query strip  S, dP -> P, dS ; P^T and dS to LDS ; bias grad to the LDS table
+      f32x4 dsr[4][4];
+      int kiy[4], kix[4], krid[4];
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) {
+        kiy[ns] = sGeoK[ns * 16 + fr][0]; kix[ns] = sGeoK[ns * 16 + fr][1]; krid[ns] = sGeoK[ns * 16 + fr][2];
+      }
+      const int dyoff = (qt - kt) * R;
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) { s[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kb = 0; kb < L::KBQ; ++kb) {
+          const uint4 fq = frag<T>(myQ, L::QROW, ms * 16, kb, HD, lane);
+          const uint4 fo = frag<T>(myDO, L::QROW, ms * 16, kb, HD, lane);
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns) {
+            const uint4 fk = frag<T>(myK, L::QROW, ns * 16, kb, HD, lane);
+            const uint4 fv = frag<T>(myV, L::QROW, ns * 16, kb, HD, lane);
+            mma16<T>(s[ns], fq, fk);
+            mma16<T>(dp[ns], fo, fv);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qn = ms * 16 + fg * 4 + r;
+          const int qiy = sGeoQ[qn][0], qix = sGeoQ[qn][1], qrid = sGeoQ[qn][2];
+          const long tq = sTokQ[qn];
+          const float lq = lse[tq * g.heads + head];
+          float dl = 0.f;
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns) {
+            float v = s[ns][r] * scale + bt[(qiy - kiy[ns] + g.ws - 1) * L2 + (qix - kix[ns] + g.ws - 1)];
+            if (qrid != krid[ns]) v += -100.0f;
+            const float p = fast_exp(v - lq);
+            s[ns][r] = p;
+            dl += p * dp[ns][r];
+          }
+          if (single) dl = group16_sum(dl);
+          else dl = delta[tq * g.heads + head];
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns) {
+            const float ds = s[ns][r] * (dp[ns][r] - dl);
+            dsr[ms][ns][r] = ds;
+            const int li = (qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1);
+            atomicAdd(&sDB[w][li], ds);
+            st_elem<T>(myDS + qn * L::TROW + (ns * 16 + fr) * E, ds);
+          }
+        }
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) st4<T>(myPT + (ns * 16 + fr) * L::TROW + (ms * 16 + fg * 4) * E, s[ns]);
+      }
+      __syncthreads();
+
+      // ---- phase B1: dV += P^T dO ;  dQ = scale * dS K
+#pragma unroll
+      for (int kb = 0; kb < L::KBT; ++kb) {
+        uint4 fb[HD / 16];
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) fb[d] = frag<T>(myDOT, L::TROW, d * 16, kb, 64, lane);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const uint4 fa = frag<T>(myPT, L::TROW, ks * 16, kb, 64, lane);
+#pragma unroll
+          for (int d = 0; d < HD / 16; ++d) mma16<T>(dv[ks][d], fa, fb[d]);
+        }
+      }
+      {
+        f32x4 dq[4][HD / 16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int d = 0; d < HD / 16; ++d) dq[i][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < L::KBT; ++kb) {
+          uint4 fb[HD / 16];
+#pragma unroll
+          for (int d = 0; d < HD / 16; ++d) fb[d] = frag<T>(myKT, L::TROW, d * 16, kb, 64, lane);
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) {
+            const uint4 fa = frag<T>(myDS, L::TROW, ms * 16, kb, 64, lane);
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d) mma16<T>(dq[ms][d], fa, fb[d]);
+          }
+        }
+        __syncthreads();   // every wave is done reading sQ / sDO / sPT of this pair
+        if (single) {
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int d = 0; d < HD / 16; ++d)
+                st_elem<T>(myQ + (ms * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dq[ms][d][r] * scale);
+        } else {
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const long tq = sTokQ[ms * 16 + fg * 4 + r];
+#pragma unroll
+              for (int d = 0; d < HD / 16; ++d)
+                atomicAdd(dq_acc + tq * g.C + head * HD + d * 16 + fr, dq[ms][d][r] * scale);
+            }
+        }
+      }
+      // ---- phase B2: dS^T (from registers) into the P^T tile, then dK += dS^T Q
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) st4<T>(myPT + (ns * 16 + fr) * L::TROW + (ms * 16 + fg * 4) * E, dsr[ms][ns]);
+      __syncthreads();
+      if (single) {   // dQ tile (staged in sQ) -> dqkv[:, 0:C]
+        for (int idx = tid; idx < 64 * CPR; idx += NT) {
+          const int r = idx / CPR, cc = idx - r * CPR;
+          const int h = cc / L::DCH, dc = cc - h * L::DCH;
+          *(uint4*)(dqkv + (long)sTokQ[r] * C3 + (hg * NW) * HD + cc * KPL) = *(const uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16);
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < L::KBT; ++kb) {
+        uint4 fb[HD / 16];
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) fb[d] = frag<T>(myQT, L::TROW, d * 16, kb, 64, lane);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const uint4 fa = frag<T>(myPT, L::TROW, ks * 16, kb, 64, lane);
+#pragma unroll
+          for (int d = 0; d < HD / 16; ++d) mma16<T>(dk[ks][d], fa, fb[d]);
+        }
+      }
+      // ---- flush the bias-gradient table when the (q tile, kv tile) offset changes
+      if (!single) {
+        __syncthreads();
+        for (int i = lane; i < LT; i += 64) {
+          const int a = i / L2, c = i - a * L2;
+          const int gy = a - (R - 1) + dyoff + g.ws - 1;
+          const float v = sDB[w][i];
+          if (gy >= 0 && gy < L2 && v != 0.f) atomicAdd(dbias_t + (long)head * L2 * L2 + gy * L2 + c, v);
+          sDB[w][i] = 0.f;
+        }
+      }
+    }
+    // ---- dK, dV of this kv tile -> staged through sK / sV -> dqkv[:, C:2C], [:, 2C:3C]
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) {
+          st_elem<T>(myK + (ks * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dk[ks][d][r] * scale);
+          st_elem<T>(myV + (ks * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dv[ks][d][r]);
+        }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CPR; idx += NT) {
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int h = cc / L::DCH, dc = cc - h * L::DCH;
+      T* dst = dqkv + (long)sTokK[r] * C3 + (hg * NW) * HD + cc * KPL;
+      *(uint4*)(dst + g.C) = *(const uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16);
+      *(uint4*)(dst + 2 * g.C) = *(const uint4*)(sV + (h * 64 + r) * L::QROW + dc * 16);
+    }
+  }
+  if (single) {
+    __syncthreads();
+    for (int i = lane; i < LT; i += 64) {
+      const float v = sDB[w][i];
+      if (v != 0.f) atomicAdd(dbias_t + (long)head * L2 * L2 + i, v);
+    }
+  }
+}
+
+bool make_geo(AttnGeo& g, int B, int H, int W, int C, int heads, int ws, int shift) {
+  if (B <= 0 || H <= 0 || W <= 0 || ws <= 0 || (H % ws) || (W % ws) || heads <= 0 || (C % heads)) return false;
+  if ((ws * ws) % 64) return false;
+  if (ws < 8 || (64 % ws && ws < 64) ) return false;           // a 64-token tile must cover whole window rows
+  if (ws > 64) return false;
+  if (shift < 0 || shift >= ws) return false;
+  g.B = B; g.H = H; g.W = W; g.C = C; g.heads = heads; g.ws = ws; g.shift = shift;
+  g.nwy = H / ws; g.nwx = W / ws; g.N = ws * ws; g.nqt = g.N / 64;
+  return true;
+}
+
+template <typename T, int HD, int NW>
+int launch_fwd(const void* qkv, const float* bias_t, void* out, float* lse, const AttnGeo& g, hipStream_t st) {
+  if (g.heads % NW) return SODT_EINVAL;
+  const long blocks = (long)g.B * g.nwy * g.nwx * g.nqt * (g.heads / NW);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, HD, NW>), dim3((unsigned)blocks), dim3(NW * 64), 0, st,
+                     (const T*)qkv, bias_t, (T*)out, lse, g);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+template <typename T, int HD, int NW>
+int launch_bwd(const void* qkv, const float* bias_t, const void* out, const void* dout, const float* lse, void* dqkv,
+               float* dbias_t, float* scratch, const AttnGeo& g, hipStream_t st) {
+  if (g.heads % NW) return SODT_EINVAL;
+  const long M = (long)g.B * g.H * g.W;
+  const int nwin = g.B * g.nwy * g.nwx;
+  float* dq_acc = nullptr; float* delta = nullptr;
+  if (g.nqt > 1) {
+    if (!scratch || !out) return SODT_EINVAL;
+    dq_acc = scratch; delta = scratch + M * g.C;
+    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3(1024), dim3(256), 0, st, (const T*)out, (const T*)dout, delta, M, g.C, g.heads);
+  }
+  const int nitems = nwin * g.nqt;
+  int gx = nitems < 1024 ? nitems : 1024;
+  hipLaunchKernelGGL((attn_bwd_kernel<T, HD, NW>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
+                     (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin);
+  if (g.nqt > 1)
+    hipLaunchKernelGGL((attn_dq_finish_kernel<T>), dim3(1024), dim3(256), 0, st, dq_acc, (T*)dqkv, M, g.C);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int sodt_window_attn_fwd(const void* qkv, const float* bias_t, void* out, float* lse,
+                                    int B, int H, int W, int C, int heads, int ws, int shift,
+                                    int dtype, sodt_stream_t st_) {
+  AttnGeo g;
+  if (!qkv || !bias_t || !out || !make_geo(g, B, H, W, C, heads, ws, shift)) return SODT_EINVAL;
+  hipStream_t st = (hipStream_t)st_;
+  const int hd = C / heads;
+  if (dtype == SODT_BF16) {
+    if (hd == 16) return launch_fwd<bf16, 16, 4>(qkv, bias_t, out, lse, g, st);
+    if (hd == 32) return launch_fwd<bf16, 32, 4>(qkv, bias_t, out, lse, g, st);
+    if (hd == 64) return launch_fwd<bf16, 64, 4>(qkv, bias_t, out, lse, g, st);
+  } else if (dtype == SODT_F32) {
+    if (hd == 16) return launch_fwd<float, 16, 4>(qkv, bias_t, out, lse, g, st);
+    if (hd == 32) return launch_fwd<float, 32, 2>(qkv, bias_t, out, lse, g, st);
+    if (hd == 64) return launch_fwd<float, 64, 2>(qkv, bias_t, out, lse, g, st);
+  }
+  return SODT_EINVAL;
+}
+
+extern "C" int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const void* out, const void* dout,
+                                    const float* lse, void* dqkv, float* dbias_t, float* dq_acc,
+                                    int B, int H, int W, int C, int heads, int ws, int shift,
+                                    int dtype, sodt_stream_t st_) {
+  AttnGeo g;
+  if (!qkv || !bias_t || !dout || !lse || !dqkv || !dbias_t || !make_geo(g, B, H, W, C, heads, ws, shift)) return SODT_EINVAL;
+  hipStream_t st = (hipStream_t)st_;
+  const int hd = C / heads;
+  if (dtype == SODT_BF16) {
+    if (hd == 16) return launch_bwd<bf16, 16, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
+    if (hd == 32) return launch_bwd<bf16, 32, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
+    if (hd == 64) return launch_bwd<bf16, 64, 1>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
+  } else if (dtype == SODT_F32) {
+    if (hd == 16) return launch_bwd<float, 16, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
+    if (hd == 32) return launch_bwd<float, 32, 1>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
+    if (hd == 64) return launch_bwd<float, 64, 1>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
+  }
+  return SODT_EINVAL;
+}

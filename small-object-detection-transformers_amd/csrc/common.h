@@ -1,0 +1,108 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+//
+// Activation dtype T is either float (the 1e-3 parity path, exact-f32 MFMA
+// v_mfma_f32_16x16x4_f32) or __bf16 (the throughput path, v_mfma_f32_16x16x32_bf16).
+// All MFMA operands are fetched as ONE 16-byte vector per lane whose elements are
+// consecutive along the contraction index k:
+//     lane l holds  A[row = l & 15][k = KPL*(l >> 4) + j],  j = 0 .. KPL-1
+//     lane l holds  B[k = KPL*(l >> 4) + j][col = l & 15]
+// with KPL = 8 (bf16) or 4 (f32).  For f32 the four elements are fed to four
+// 16x16x4 MFMAs (element j -> MFMA j); because A and B use the same k permutation
+// the sum over the 16 k's of one call is exact.  The accumulator layout is the
+// dtype-independent 16x16 C/D map: acc[r] <-> row = 4*(l >> 4) + r, col = l & 15.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define SODT_OK 0
+#define SODT_EINVAL 1
+
+template <typename T> struct TT;
+template <> struct TT<float> {
+  static constexpr int KPL = 4;     // elements per 16-byte chunk
+  static constexpr int MMA_K = 16;  // contraction depth of one mma16() call
+  static constexpr int SZ = 4;
+};
+template <> struct TT<bf16> {
+  static constexpr int KPL = 8;
+  static constexpr int MMA_K = 32;
+  static constexpr int SZ = 2;
+};
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32 (RNE, NaN kept)
+
+// one 16x16 tile update: acc += A(16 x MMA_K) * B(MMA_K x 16)
+template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void mma16<bf16>(f32x4& acc, const uint4& a, const uint4& b) {
+  union { uint4 u; bf16x8 v; } ua, ub;
+  ua.u = a; ub.u = b;
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// 16-byte chunk <-> KPL floats
+template <typename T> __device__ __forceinline__ void unpack(const uint4& u, float* f);
+template <> __device__ __forceinline__ void unpack<float>(const uint4& u, float* f) {
+  f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+}
+template <> __device__ __forceinline__ void unpack<bf16>(const uint4& u, float* f) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  union { bf16 b; uint16_t u; } a, b;
+  a.b = (bf16)lo; b.b = (bf16)hi;
+  return (uint32_t)a.u | ((uint32_t)b.u << 16);
+}
+template <typename T> __device__ __forceinline__ uint4 pack(const float* f);
+template <> __device__ __forceinline__ uint4 pack<float>(const float* f) {
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 pack<bf16>(const float* f) {
+  return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// reductions inside a 16-lane group (lanes sharing l >> 4) and a full wave
+__device__ __forceinline__ float group16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
+  v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+  return v;
+}
+
+// XCD-aware, bijective block remap (8 XCDs, blocks dealt round-robin): logical tiles
+// that are adjacent run on one XCD and share its L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

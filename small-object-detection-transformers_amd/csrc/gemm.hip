@@ -1,0 +1,492 @@
+// MFMA GEMMs of the hot path (gfx950).
+//
+//   sodt_gemm_nt : C[M][N] = epilogue( A[M][K] @ W[N][K]^T )       forward + input grads
+//   sodt_gemm_tn : dW[N][K] += dY[M][N]^T @ X[M][K]  (+ dbias)      weight grads
+//
+// A / X are described as K-segments with a spatial row map (include/sodt_hip.h), so
+// 1x1 / 2x2 / 3x3 convs, PatchMerging, upsample+concat and their transposes are all
+// this one kernel: implicit GEMM, nothing is materialised.
+//
+// NT kernel: 128x128 output tile, 4 waves (2x2, 64x64 each = 4x4 MFMA 16x16 tiles),
+// K-step of 128 bytes per row (64 bf16 / 32 f32), LDS double buffer with an
+// XOR-swizzled 16-byte-chunk layout (chunk ^= row & 7), register-staged prefetch of
+// the next K-step under the MFMAs of the current one, accumulators staged through LDS
+// (padded rows) so that the epilogue reads/writes whole 16-byte row chunks.
+// Roofline: MFMA for K >= 384; at K = 192 (stage 1) it is HBM-bound.
+#include "common.h"
+#include "../../include/sodt_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, ROWB = 128;          // ROWB: bytes per LDS row per K-step
+constexpr int STAGE_BYTES = BM * ROWB;                 // 16 KiB per operand per stage
+constexpr int EPI_LD = 132;                            // padded f32 row of the staged accumulator tile
+constexpr int NT_LDS = BM * EPI_LD * 4;                // 67584 B >= 4 * STAGE_BYTES
+
+struct RowGeo { int b, y, x; bool ok; };
+
+__device__ __forceinline__ long seg_src_row(const sodt_seg& s, const RowGeo& r, int spatial, long m) {
+  if (!r.ok) return -1;
+  if (!spatial) return m;
+  const int yy = r.y * s.mul + s.dy, xx = r.x * s.mul + s.dx;
+  if (yy < 0 || xx < 0) return -1;
+  const int yi = yy >> s.shr, xi = xx >> s.shr;
+  if (yi >= s.Hi || xi >= s.Wi) return -1;
+  return ((long)r.b * s.Hi + yi) * s.Wi + xi;
+}
+
+// static-index select so the kernarg segment table stays in SGPRs
+__device__ __forceinline__ sodt_seg pick_seg(const sodt_aspec& a, int i) {
+  sodt_seg s = a.s[0];
+#pragma unroll
+  for (int j = 1; j < SODT_MAX_SEG; ++j)
+    if (i == j) s = a.s[j];
+  return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g) {
+  constexpr int KPL = TT<T>::KPL;
+  constexpr int BK = 8 * KPL;                 // elements per K-step
+  constexpr int SZ = TT<T>::SZ;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NT_LDS];
+  unsigned char* sA = smem;                   // [2][STAGE_BYTES]
+  unsigned char* sB = smem + 2 * STAGE_BYTES; // [2][STAGE_BYTES]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int ntn = (g.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = tile % ntn, tm = tile / ntn;
+  const long m0 = (long)tm * BM;
+  const int n0 = tn * BN;
+
+  // ---- loader state: 4 rows x one 16-byte chunk per thread and operand
+  const int lrow = tid >> 3, lch = tid & 7;
+  RowGeo geo[4];
+  const int hw = g.a.Ho * g.a.Wo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long m = m0 + lrow + 32 * i;
+    geo[i].ok = m < g.M;
+    geo[i].b = 0; geo[i].y = 0; geo[i].x = 0;
+    if (g.a.spatial && geo[i].ok) {
+      const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+      geo[i].b = b; geo[i].y = rem / g.a.Wo; geo[i].x = rem - geo[i].y * g.a.Wo;
+    }
+  }
+  int a_seg = 0, a_off = lch * KPL;
+  sodt_seg seg = g.a.s[0];
+  long srow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) srow[i] = seg_src_row(seg, geo[i], g.a.spatial, m0 + lrow + 32 * i);
+
+  uint4 ra[4], rb[4];
+  const int nk = (g.K + BK - 1) / BK;
+
+  auto load_regs = [&](int kt) {
+    while (a_seg < g.a.nseg && a_off >= seg.klen) {
+      a_off -= seg.klen;
+      ++a_seg;
+      if (a_seg < g.a.nseg) {
+        seg = pick_seg(g.a, a_seg);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) srow[i] = seg_src_row(seg, geo[i], g.a.spatial, m0 + lrow + 32 * i);
+      }
+    }
+    const bool kin = a_seg < g.a.nseg;
+    const T* ap = (const T*)seg.p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (kin && srow[i] >= 0) ra[i] = *(const uint4*)(ap + srow[i] * seg.ld + a_off);
+    }
+    a_off += BK;
+    const int k = kt * BK + lch * KPL;
+    const T* wp = (const T*)g.W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + lrow + 32 * i;
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (n < g.N && k < g.K) rb[i] = *(const uint4*)(wp + (long)n * g.ldw + k);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = lrow + 32 * i;
+      const int off = r * ROWB + ((lch ^ (r & 7)) << 4);
+      *(uint4*)(sA + buf * STAGE_BYTES + off) = ra[i];
+      *(uint4*)(sB + buf * STAGE_BYTES + off) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_regs(0);
+  store_lds(0);
+  __syncthreads();
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_regs(kt + 1);
+    const unsigned char* a_s = sA + buf * STAGE_BYTES;
+    const unsigned char* b_s = sB + buf * STAGE_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      uint4 fa[4], fb[4];
+      const int ch = kb * 4 + fg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wr * 64 + i * 16 + fr;
+        fa[i] = *(const uint4*)(a_s + r * ROWB + ((ch ^ (r & 7)) << 4));
+        const int c = wc * 64 + i * 16 + fr;
+        fb[i] = *(const uint4*)(b_s + c * ROWB + ((ch ^ (c & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], fa[i], fb[j]);
+    }
+    if (kt + 1 < nk) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- stage accumulators (f32) through LDS: rows padded to EPI_LD floats
+  float* sC = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sC[(wr * 64 + i * 16 + fg * 4 + r) * EPI_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
+  __syncthreads();
+
+  const int flags = g.flags;
+  if (flags & SODT_EPI_STATS) {
+    if (tid < BN && n0 + tid < g.N) {
+      double s = 0.0, s2 = 0.0;
+      const int rmax = (int)((g.M - m0) < BM ? (g.M - m0) : BM);
+      for (int r = 0; r < rmax; ++r) {
+        const float v = sC[r * EPI_LD + tid];
+        s += v; s2 += (double)v * v;
+      }
+      atomicAdd(g.stats + n0 + tid, s);
+      atomicAdd(g.stats + g.N + n0 + tid, s2);
+    }
+  }
+
+  if (flags & SODT_EPI_DETECT) {
+    // Detect.forward's view(bs,na,no,ny,nx).permute(0,1,3,4,2): out[((b*na+a)*HW+p)*no+o] = z[b*HW+p][a*no+o] + bias
+    float* out = (float*)g.C;
+    for (int idx = tid; idx < BM * BN; idx += 256) {
+      const int r = idx >> 7, c = idx & 127;
+      const long m = m0 + r; const int n = n0 + c;
+      if (m < g.M && n < g.N) {
+        float v = sC[r * EPI_LD + c];
+        if (flags & SODT_EPI_BIAS) v += g.bias[n];
+        const long b = m / g.det_hw, p = m - b * g.det_hw;
+        const int a = n / g.det_no, o = n - a * g.det_no;
+        out[((b * g.det_na + a) * g.det_hw + p) * g.det_no + o] = v;
+      }
+    }
+    return;
+  }
+
+  const bool out32 = (flags & SODT_EPI_OUT_F32) != 0;
+  constexpr int CPR = BN / KPL;   // chunks per row
+  for (int idx = tid; idx < BM * CPR; idx += 256) {
+    const int r = idx / CPR, c = (idx - r * CPR) * KPL;
+    const long m = m0 + r; const int n = n0 + c;
+    if (m >= g.M || n >= g.N) continue;
+    float v[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; j += 4) {
+      const float4 t = *(const float4*)(sC + r * EPI_LD + c + j);
+      v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+    }
+    const bool full = (n + KPL <= g.N);
+    if (flags & SODT_EPI_BIAS) {
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) if (full || n + j < g.N) v[j] += g.bias[n + j];
+    }
+    if (flags & SODT_EPI_AFFINE_SILU) {
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) if (full || n + j < g.N) {
+        const float a = v[j] * g.scale[n + j] + g.shift[n + j];
+        v[j] = a * sigmoid_f(a);
+      }
+    }
+    if (flags & SODT_EPI_DGELU) {
+      float x[KPL];
+      const T* ap = (const T*)g.aux + m * g.ldaux + n;
+      if (full) { unpack<T>(*(const uint4*)ap, x); }
+      else { for (int j = 0; j < KPL; ++j) x[j] = (n + j < g.N) ? to_f(ap[j]) : 0.f; }
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) v[j] *= dgelu_f(x[j]);
+    }
+    if (flags & SODT_EPI_RESID) {
+      const long rr = g.rmod > 0 ? (m % g.rmod) : m;
+      float x[KPL];
+      const T* rp = (const T*)g.R + rr * g.ldr + n;
+      if (full) { unpack<T>(*(const uint4*)rp, x); }
+      else { for (int j = 0; j < KPL; ++j) x[j] = (n + j < g.N) ? to_f(rp[j]) : 0.f; }
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) v[j] += x[j];
+    }
+    long orow = m;
+    if (g.oscatter) {
+      const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+      const int y = rem / g.a.Wo, x = rem - y * g.a.Wo;
+      orow = ((long)b * g.OH + y * g.omul + g.ody) * g.OW + x * g.omul + g.odx;
+    }
+    if (out32) {
+      float* cp = (float*)g.C + orow * g.ldc + n;
+      for (int j = 0; j < KPL; ++j) if (full || n + j < g.N) cp[j] = v[j];
+    } else {
+      T* cp = (T*)g.C + orow * g.ldc + n;
+      if (full) *(uint4*)cp = pack<T>(v);
+      else for (int j = 0; j < KPL; ++j) if (n + j < g.N) cp[j] = from_f<T>(v[j]);
+      if (flags & SODT_EPI_GELU_DUAL) {
+        float a[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) a[j] = gelu_f(v[j]);
+        T* c2 = (T*)g.C2 + orow * g.ldc2 + n;
+        if (full) *(uint4*)c2 = pack<T>(a);
+        else for (int j = 0; j < KPL; ++j) if (n + j < g.N) c2[j] = from_f<T>(a[j]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// TN: dW[n][k] += sum_m dY[m][n] * X[m][k].  128(n) x 128(k) tile, the M range of this
+// split walked in steps of BMS rows (64 bf16 / 32 f32).  Both operands are consumed
+// "transposed" (contraction index = LDS row): bf16 through ds_read_b64_tr_b16, f32
+// through four strided ds_read_b32.  LDS rows are padded by 16 bytes.
+// ---------------------------------------------------------------------------------
+template <typename T> struct TNGeo;
+template <> struct TNGeo<bf16> { static constexpr int BMS = 64, LDSROW = 128 * 2 + 16; };
+template <> struct TNGeo<float> { static constexpr int BMS = 32, LDSROW = 128 * 4 + 16; };
+
+template <typename T>
+__device__ __forceinline__ uint4 tn_frag(const unsigned char* tile, int kb, int col0, int lane);
+template <>
+__device__ __forceinline__ uint4 tn_frag<bf16>(const unsigned char* tile, int kb, int col0, int lane) {
+  // k (= LDS row) = kb*32 + 8*(lane>>4) + j ; column = col0 + (lane & 15)
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned char* a = tile + (kb * 32 + 8 * g + q) * TNGeo<bf16>::LDSROW + (col0 + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  union { s16x4 v; uint2 u; } lo, hi;
+  lo.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  hi.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * TNGeo<bf16>::LDSROW));
+  return make_uint4(lo.u.x, lo.u.y, hi.u.x, hi.u.y);
+}
+template <>
+__device__ __forceinline__ uint4 tn_frag<float>(const unsigned char* tile, int kb, int col0, int lane) {
+  const int g = lane >> 4, c = col0 + (lane & 15);
+  const unsigned char* a = tile + (kb * 16 + 4 * g) * TNGeo<float>::LDSROW + c * 4;
+  uint4 r;
+  r.x = *(const uint32_t*)(a);
+  r.y = *(const uint32_t*)(a + TNGeo<float>::LDSROW);
+  r.z = *(const uint32_t*)(a + 2 * TNGeo<float>::LDSROW);
+  r.w = *(const uint32_t*)(a + 3 * TNGeo<float>::LDSROW);
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const sodt_gemm_tn_args g) {
+  constexpr int KPL = TT<T>::KPL;
+  constexpr int BMS = TNGeo<T>::BMS;
+  constexpr int LDSROW = TNGeo<T>::LDSROW;
+  constexpr int TILE = BMS * LDSROW;
+  constexpr int CPR = 128 / KPL;          // 16-byte chunks per tile row
+  constexpr int RPT = 256 / CPR;          // rows covered per pass by the 256 threads
+  constexpr int NLD = BMS / RPT;          // = 4 chunks per thread and operand
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];
+  unsigned char* sY = smem;               // [2][TILE]
+  unsigned char* sX = smem + 2 * TILE;    // [2][TILE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int ntk = (g.K + 127) / 128;
+  const int tk = blockIdx.x % ntk, tn = blockIdx.x / ntk;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const long rows_per = (((g.M + g.splits - 1) / g.splits) + BMS - 1) / BMS * BMS;
+  const long mbeg = (long)blockIdx.y * rows_per;
+  const long mend = (mbeg + rows_per < g.M) ? (mbeg + rows_per) : g.M;
+  if (mbeg >= mend) return;
+
+  // wave-level skip of sub-tiles entirely outside N / K (N = 192, 576 ... tails)
+  const bool wave_live = (n0 + wr * 64 < g.N) && (k0 + wc * 64 < g.K);
+
+  // loader: this thread's chunk column is fixed for the whole kernel
+  const int lrow = tid / CPR, lch = tid - lrow * CPR;
+  const int ycol = n0 + lch * KPL;
+  const bool yok = ycol < g.N;
+  const int xcol = k0 + lch * KPL;
+  // locate the X segment of this column
+  int xs_i = -1, xs_off = 0;
+  {
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < SODT_MAX_SEG; ++j) {
+      if (j < g.x.nseg) {
+        if (xs_i < 0 && xcol < base + g.x.s[j].klen && xcol < g.K) { xs_i = j; xs_off = xcol - base; }
+        base += g.x.s[j].klen;
+      }
+    }
+  }
+  const sodt_seg seg = pick_seg(g.x, xs_i < 0 ? 0 : xs_i);
+  const int hw = g.x.Ho * g.x.Wo;
+
+  uint4 ry[NLD], rx[NLD];
+  auto load_regs = [&](long mb) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const long m = mb + lrow + RPT * i;
+      ry[i] = make_uint4(0, 0, 0, 0);
+      rx[i] = make_uint4(0, 0, 0, 0);
+      if (m < mend) {
+        if (yok) ry[i] = *(const uint4*)((const T*)g.dY + m * g.ldy + ycol);
+        if (xs_i >= 0) {
+          RowGeo r; r.ok = true; r.b = 0; r.y = 0; r.x = 0;
+          if (g.x.spatial) {
+            const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+            r.b = b; r.y = rem / g.x.Wo; r.x = rem - r.y * g.x.Wo;
+          }
+          const long sr = seg_src_row(seg, r, g.x.spatial, m);
+          if (sr >= 0) rx[i] = *(const uint4*)((const T*)seg.p + sr * seg.ld + xs_off);
+        }
+      }
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int off = (lrow + RPT * i) * LDSROW + lch * 16;
+      *(uint4*)(sY + buf * TILE + off) = ry[i];
+      *(uint4*)(sX + buf * TILE + off) = rx[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool do_bias = (g.dbias != nullptr) && (tk == 0) && tid < 128 && (n0 + tid < g.N);
+
+  const int nsteps = (int)((mend - mbeg + BMS - 1) / BMS);
+  load_regs(mbeg);
+  store_lds(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_regs(mbeg + (long)(s + 1) * BMS);
+    const unsigned char* ty = sY + buf * TILE;
+    const unsigned char* tx = sX + buf * TILE;
+    if (wave_live) {
+#pragma unroll
+      for (int kb = 0; kb < BMS / TT<T>::MMA_K; ++kb) {
+        uint4 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fa[i] = tn_frag<T>(ty, kb, wr * 64 + i * 16, lane);
+          fb[i] = tn_frag<T>(tx, kb, wc * 64 + i * 16, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], fa[i], fb[j]);
+      }
+    }
+    if (do_bias) {
+      for (int r = 0; r < BMS; ++r) bsum += to_f(*(const T*)(ty + r * LDSROW + tid * sizeof(T)));
+    }
+    if (s + 1 < nsteps) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (do_bias) atomicAdd(g.dbias + n0 + tid, bsum);
+  if (!wave_live) return;
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wc * 64 + j * 16 + fr;
+      if (k >= g.K) continue;
+      int kk = k;
+      if (g.kperm_t > 1) kk = (k % g.kperm_c) * g.kperm_t + k / g.kperm_c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wr * 64 + i * 16 + fg * 4 + r;
+        if (n < g.N) atomicAdd(g.dW + (long)n * g.lddw + kk, acc[i][j][r]);
+      }
+    }
+}
+
+bool aspec_ok(const sodt_aspec& a, int K, int kpl) {
+  if (a.nseg < 1 || a.nseg > SODT_MAX_SEG) return false;
+  long tot = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    const sodt_seg& s = a.s[i];
+    if (s.klen <= 0 || (s.klen % kpl) || (s.ld % kpl) || (((uintptr_t)s.p) & 15)) return false;
+    if (a.spatial && (s.Hi <= 0 || s.Wi <= 0 || s.mul < 1 || s.shr < 0)) return false;
+    tot += s.klen;
+  }
+  if (a.spatial && (a.Ho <= 0 || a.Wo <= 0)) return false;
+  return tot == K;
+}
+
+}  // namespace
+
+extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st) {
+  if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0) return SODT_EINVAL;
+  const int kpl = dtype == SODT_BF16 ? 8 : 4;
+  if (!aspec_ok(g->a, g->K, kpl)) return SODT_EINVAL;
+  if ((g->ldw % kpl) || (((uintptr_t)g->W) & 15) || !g->C) return SODT_EINVAL;
+  if (!(g->flags & SODT_EPI_DETECT)) {
+    const int okpl = (g->flags & SODT_EPI_OUT_F32) ? 1 : kpl;
+    if ((g->ldc % okpl) || (((uintptr_t)g->C) & 15)) return SODT_EINVAL;
+  } else if (g->det_na * g->det_no != g->N || g->det_hw <= 0) return SODT_EINVAL;
+  if ((g->flags & SODT_EPI_BIAS) && !g->bias) return SODT_EINVAL;
+  if ((g->flags & SODT_EPI_RESID) && (!g->R || (g->ldr % kpl))) return SODT_EINVAL;
+  if ((g->flags & SODT_EPI_DGELU) && (!g->aux || (g->ldaux % kpl))) return SODT_EINVAL;
+  if ((g->flags & SODT_EPI_GELU_DUAL) && (!g->C2 || (g->ldc2 % kpl))) return SODT_EINVAL;
+  if ((g->flags & SODT_EPI_STATS) && !g->stats) return SODT_EINVAL;
+  if ((g->flags & SODT_EPI_AFFINE_SILU) && (!g->scale || !g->shift)) return SODT_EINVAL;
+  if (g->oscatter && !g->a.spatial) return SODT_EINVAL;
+  const long tiles = ((long)(g->M + BM - 1) / BM) * ((g->N + BN - 1) / BN);
+  if (tiles > 0x7fffffffL) return SODT_EINVAL;
+  dim3 grid((unsigned)tiles), block(256);
+  if (dtype == SODT_BF16) {
+    hipLaunchKernelGGL(gemm_nt_kernel<bf16>, grid, block, 0, (hipStream_t)st, *g);
+  } else if (dtype == SODT_F32) {
+    hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, (hipStream_t)st, *g);
+  } else return SODT_EINVAL;
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+extern "C" int sodt_gemm_tn(const sodt_gemm_tn_args* g, int dtype, sodt_stream_t st) {
+  if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->splits < 1 || !g->dW || !g->dY) return SODT_EINVAL;
+  const int kpl = dtype == SODT_BF16 ? 8 : 4;
+  if (!aspec_ok(g->x, g->K, kpl)) return SODT_EINVAL;
+  if ((g->ldy % kpl) || (g->N % kpl) || (((uintptr_t)g->dY) & 15)) return SODT_EINVAL;
+  if (g->kperm_t > 1 && (g->kperm_c <= 0 || g->kperm_c * g->kperm_t != g->K)) return SODT_EINVAL;
+  const int tiles = ((g->N + 127) / 128) * ((g->K + 127) / 128);
+  dim3 grid(tiles, g->splits), block(256);
+  if (dtype == SODT_BF16) {
+    hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, block, 0, (hipStream_t)st, *g);
+  } else if (dtype == SODT_F32) {
+    hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, block, 0, (hipStream_t)st, *g);
+  } else return SODT_EINVAL;
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}

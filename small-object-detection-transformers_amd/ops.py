@@ -1,0 +1,256 @@
+"""Thin Python wrappers over the C ABI (include/sodt_hip.h).
+
+Every wrapper builds the argument record once, launches on torch's current stream and,
+when a ``Recorder`` is active, also appends ``(cfunc, args)`` to it so that the engine
+can replay a whole forward / backward with ~1 us of host work per kernel (shapes and
+buffers are static per (batch, resolution, dtype) plan).  PyTorch is used only for
+device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+_lib = L.load()
+
+_active_recorder: Optional[list] = None
+
+
+class Recorder:
+    """with Recorder() as rec: ...ops...  -> rec.calls can be replayed with replay()."""
+
+    def __init__(self):
+        self.calls: List[Tuple] = []
+        self.keep: List = []       # tensors / structs that must outlive the plan
+
+    def __enter__(self):
+        global _active_recorder
+        assert _active_recorder is None, "nested recorders are not supported"
+        _active_recorder = self.calls
+        return self
+
+    def __exit__(self, *exc):
+        global _active_recorder
+        _active_recorder = None
+        return False
+
+
+def replay(calls: Sequence[Tuple], stream: Optional[int] = None) -> None:
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
+    for fn, args, name in calls:
+        rc = fn(*args, st)
+        if rc != 0:
+            raise RuntimeError(f"{name} failed with status {rc}")
+
+
+def _launch(name: str, *args) -> None:
+    fn = getattr(_lib, name)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = fn(*args, st)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with status {rc} (unsupported shape/alignment, see include/sodt_hip.h)")
+    if _active_recorder is not None:
+        _active_recorder.append((fn, args, name))
+
+
+def dt_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    if t.dtype == torch.float32:
+        return L.F32
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class SegSpec:
+    """One K-segment: a [rows][ld] token-major tensor view starting at channel ``coff``."""
+    __slots__ = ("t", "klen", "coff", "dy", "dx", "mul", "shr", "Hi", "Wi", "ld")
+
+    def __init__(self, t: torch.Tensor, klen: Optional[int] = None, coff: int = 0, dy: int = 0, dx: int = 0,
+                 mul: int = 1, shr: int = 0, Hi: int = 0, Wi: int = 0, ld: Optional[int] = None):
+        self.t = t
+        self.ld = t.shape[-1] if ld is None else ld
+        self.klen = (self.ld - coff) if klen is None else klen
+        self.coff, self.dy, self.dx, self.mul, self.shr, self.Hi, self.Wi = coff, dy, dx, mul, shr, Hi, Wi
+
+
+def _fill_aspec(a: L.ASpec, segs: Sequence[SegSpec], spatial: Optional[Tuple[int, int]]):
+    assert 1 <= len(segs) <= L.MAX_SEG
+    es = segs[0].t.element_size()
+    for i, s in enumerate(segs):
+        d = a.s[i]
+        d.p = s.t.data_ptr() + s.coff * es
+        d.ld, d.klen, d.dy, d.dx, d.mul, d.shr, d.Hi, d.Wi = s.ld, s.klen, s.dy, s.dx, s.mul, s.shr, s.Hi, s.Wi
+    a.nseg = len(segs)
+    if spatial is None:
+        a.spatial, a.Ho, a.Wo = 0, 1, 1
+    else:
+        a.spatial, a.Ho, a.Wo = 1, spatial[0], spatial[1]
+
+
+def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *,
+            ldw: Optional[int] = None, ldc: Optional[int] = None, c_off: int = 0,
+            spatial: Optional[Tuple[int, int]] = None, bias: Optional[torch.Tensor] = None,
+            resid: Optional[torch.Tensor] = None, ldr: Optional[int] = None, r_off: int = 0, rmod: int = 0,
+            gelu_out: Optional[torch.Tensor] = None, dgelu_aux: Optional[torch.Tensor] = None,
+            stats: Optional[torch.Tensor] = None, affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+            out_f32: bool = False, detect: Optional[Tuple[int, int, int]] = None,
+            oscatter: Optional[Tuple[int, int, int, int, int]] = None, w_off: int = 0) -> None:
+    """out[M][N] = epilogue(concat_k(segs) @ W[N][K]^T); see SODT_EPI_* in include/sodt_hip.h."""
+    g = L.GemmArgs()
+    _fill_aspec(g.a, segs, spatial)
+    es = W.element_size()
+    g.W = W.data_ptr() + w_off * es
+    g.ldw = W.shape[-1] if ldw is None else ldw
+    oes = 4 if (out_f32 or detect is not None) else es
+    g.C = out.data_ptr() + c_off * oes
+    g.ldc = (out.shape[-1] if ldc is None else ldc)
+    flags = 0
+    if bias is not None:
+        flags |= L.EPI_BIAS
+        g.bias = bias.data_ptr()
+    if resid is not None:
+        flags |= L.EPI_RESID
+        g.R = resid.data_ptr() + r_off * es
+        g.ldr = resid.shape[-1] if ldr is None else ldr
+        g.rmod = rmod
+    if gelu_out is not None:
+        flags |= L.EPI_GELU_DUAL
+        g.C2 = gelu_out.data_ptr()
+        g.ldc2 = gelu_out.shape[-1]
+    if dgelu_aux is not None:
+        flags |= L.EPI_DGELU
+        g.aux = dgelu_aux.data_ptr()
+        g.ldaux = dgelu_aux.shape[-1]
+    if stats is not None:
+        flags |= L.EPI_STATS
+        g.stats = stats.data_ptr()
+    if affine is not None:
+        flags |= L.EPI_AFFINE_SILU
+        g.scale, g.shift = affine[0].data_ptr(), affine[1].data_ptr()
+    if out_f32:
+        flags |= L.EPI_OUT_F32
+    if detect is not None:
+        flags |= L.EPI_DETECT
+        g.det_na, g.det_no, g.det_hw = detect
+    if oscatter is not None:
+        g.oscatter = 1
+        g.omul, g.ody, g.odx, g.OH, g.OW = oscatter
+    g.M, g.N, g.K, g.flags = M, N, K, flags
+    _launch("sodt_gemm_nt", C.byref(g), dt_code(W))
+
+
+def tn_splits(M: int, N: int, K: int) -> int:
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    return max(1, min(M // 256 if M >= 256 else 1, (1536 + tiles - 1) // tiles))
+
+
+def gemm_tn(dY: torch.Tensor, segs: Sequence[SegSpec], dW: torch.Tensor, M: int, N: int, K: int, *,
+            ldy: Optional[int] = None, y_off: int = 0, spatial: Optional[Tuple[int, int]] = None,
+            dbias: Optional[torch.Tensor] = None, lddw: Optional[int] = None, kperm: Optional[Tuple[int, int]] = None,
+            splits: Optional[int] = None) -> None:
+    """dW[N][K] (f32) += dY[M][N]^T @ concat_k(segs); dbias[N] += column sums of dY."""
+    g = L.GemmTnArgs()
+    g.dY = dY.data_ptr() + y_off * dY.element_size()
+    g.ldy = dY.shape[-1] if ldy is None else ldy
+    _fill_aspec(g.x, segs, spatial)
+    assert dW.dtype == torch.float32
+    g.dW = dW.data_ptr()
+    g.lddw = K if lddw is None else lddw
+    g.dbias = _p(dbias)
+    g.M, g.N, g.K = M, N, K
+    if kperm is not None:
+        g.kperm_c, g.kperm_t = kperm
+    g.splits = tn_splits(M, N, K) if splits is None else splits
+    _launch("sodt_gemm_tn", C.byref(g), dt_code(dY))
+
+
+def layernorm_fwd(x, gamma, beta, y, stats, M, Cc):
+    _launch("sodt_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(stats), M, Cc, dt_code(x))
+
+
+def layernorm_bwd(dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, Cc):
+    _launch("sodt_layernorm_bwd", _p(dy), _p(x), _p(stats), _p(gamma), _p(dres), _p(dx), _p(dgamma), _p(dbeta),
+            M, Cc, dt_code(x))
+
+
+def window_attn_fwd(qkv, bias_t, out, lse, B, H, W, Cc, heads, ws, shift):
+    _launch("sodt_window_attn_fwd", _p(qkv), _p(bias_t), _p(out), _p(lse), B, H, W, Cc, heads, ws, shift, dt_code(qkv))
+
+
+def window_attn_bwd(qkv, bias_t, out, dout, lse, dqkv, dbias_t, scratch, B, H, W, Cc, heads, ws, shift):
+    _launch("sodt_window_attn_bwd", _p(qkv), _p(bias_t), _p(out), _p(dout), _p(lse), _p(dqkv), _p(dbias_t), _p(scratch),
+            B, H, W, Cc, heads, ws, shift, dt_code(qkv))
+
+
+def frontend_fwd(rgb, ir_plane, ir_bstride, w, b, gamma, beta, out, B, S, ca_ws=1):
+    _launch("sodt_frontend_fwd", _p(rgb), _p(ir_plane), ir_bstride, _p(w), _p(b), _p(gamma), _p(beta), _p(out),
+            B, S, ca_ws, dt_code(out))
+
+
+def frontend_bwd(rgb, ir_plane, ir_bstride, w, b, gamma, beta, dout, dw, db, dgamma, dbeta, B, S, ca_ws=1):
+    _launch("sodt_frontend_bwd", _p(rgb), _p(ir_plane), ir_bstride, _p(w), _p(b), _p(gamma), _p(beta), _p(dout),
+            _p(dw), _p(db), _p(dgamma), _p(dbeta), B, S, ca_ws, dt_code(dout))
+
+
+def bn_finalize(stats, mean_rstd, running_mean, running_var, count, Cc, eps, momentum):
+    _launch("sodt_bn_finalize", _p(stats), _p(mean_rstd), _p(running_mean), _p(running_var), count, Cc,
+            C.c_float(eps), C.c_float(momentum))
+
+
+def bn_affine(mean_rstd, gamma, beta, scale, shift, Cc):
+    _launch("sodt_bn_affine", _p(mean_rstd), _p(gamma), _p(beta), _p(scale), _p(shift), Cc)
+
+
+def bn_silu_fwd(z, mean_rstd, gamma, beta, y, ldy, M, Cc):
+    _launch("sodt_bn_silu_fwd", _p(z), _p(mean_rstd), _p(gamma), _p(beta), _p(y), ldy, M, Cc, dt_code(z))
+
+
+def bn_silu_bwd_reduce(dy, lddy, z, mean_rstd, gamma, beta, red, M, Cc, dy_off=0):
+    _launch("sodt_bn_silu_bwd_reduce", dy.data_ptr() + dy_off * dy.element_size(), lddy, _p(z), _p(mean_rstd), _p(gamma),
+            _p(beta), _p(red), M, Cc, dt_code(z))
+
+
+def bn_silu_bwd_apply(dy, lddy, z, mean_rstd, gamma, beta, red, dz, dgamma, dbeta, M, Cc, dy_off=0):
+    _launch("sodt_bn_silu_bwd_apply", dy.data_ptr() + dy_off * dy.element_size(), lddy, _p(z), _p(mean_rstd), _p(gamma),
+            _p(beta), _p(red), _p(dz), _p(dgamma), _p(dbeta), M, Cc, dt_code(z))
+
+
+def copy_rows(src, lds, dst, ldd, B, Ho, Wo, shr, Cc, dst_off=0):
+    _launch("sodt_copy_rows", _p(src), lds, dst.data_ptr() + dst_off * dst.element_size(), ldd, B, Ho, Wo, shr, Cc, dt_code(src))
+
+
+def gather_sum_rows(d, ldd, dsrc, lds, B, Hs, Ws, shr, Cc, accumulate=False, d_off=0):
+    _launch("sodt_gather_sum_rows", d.data_ptr() + d_off * d.element_size(), ldd, _p(dsrc), lds, B, Hs, Ws, shr, Cc,
+            1 if accumulate else 0, dt_code(d))
+
+
+def detect_unpermute(dpred, dz, ldz, B, HW, na, no):
+    _launch("sodt_detect_unpermute", _p(dpred), _p(dz), ldz, B, HW, na, no, dt_code(dz))
+
+
+def detect_decode(raw, anchor_grid, z, B, na, ny, nx, no, stride):
+    _launch("sodt_detect_decode", _p(raw), _p(anchor_grid), _p(z), B, na, ny, nx, no, C.c_float(stride))
+
+
+def prep_weights(table_dev, n, max_elems, dtype_code):
+    _launch("sodt_prep_weights", _p(table_dev), n, max_elems, dtype_code)
+
+
+def transpose_f32(src, dst, rows, cols, accumulate=False):
+    _launch("sodt_transpose_f32", _p(src), _p(dst), rows, cols, 1 if accumulate else 0)
+
+
+def cast(src, dst, n):
+    _launch("sodt_cast", _p(src), _p(dst), n, dt_code(src), dt_code(dst))
+
+
+def version() -> str:
+    return _lib.sodt_version().decode()
