@@ -83,7 +83,7 @@ typedef struct {
 int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st);
 
 typedef struct {
-  const void* dY; int ldy;      /* [M][N] run dtype */
+  const void* dY; int ldy;      /* [M][N] run dtype; ldy >= N rounded up to 16 bytes (pad columns must be zero) */
   sodt_aspec x;                 /* X [M][K] as K-segments (same row mapping as the forward A) */
   float* dW; int lddw;          /* [N][K] f32, accumulated with atomics (zero it first) */
   float* dbias;                 /* [N] f32 or NULL: += column sums of dY */
@@ -114,7 +114,8 @@ int sodt_window_attn_fwd(const void* qkv, const float* bias_t, void* out, float*
                          int B, int H, int W, int C, int heads, int ws, int shift,
                          int dtype, sodt_stream_t st);
 /* dqkv from dout (recomputes P); dbias_t accumulated with atomics; dq_acc is an f32
- * [B*H*W][C] scratch needed (and zeroed by the caller) only when ws*ws > 64. */
+ * scratch of B*H*W*(C + heads) floats needed only when ws*ws > 64; its first B*H*W*C
+ * floats must be zero on entry and are left zero on exit. */
 int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const void* out, const void* dout,
                          const float* lse, void* dqkv, float* dbias_t, float* dq_acc,
                          int B, int H, int W, int C, int heads, int ws, int shift,
@@ -177,8 +178,15 @@ typedef struct {
 } sodt_prep_desc;
 int sodt_prep_weights(const sodt_prep_desc* table_dev, int n, int max_elems, int dtype, sodt_stream_t st);
 
-/* bias table (L, heads) f32 -> (heads, L) f32, and the reverse accumulate for its gradient */
+/* hipMemsetAsync(p, 0, bytes) on the stream (statistics / gradient accumulators) */
+int sodt_memset_zero(void* p, long bytes, sodt_stream_t st);
+
+/* bias table (L, heads) f32 -> (heads, L) f32, and the reverse accumulate for its gradient
+ * (accumulate: 0 = store, 1 = add, 2 = add and clear the source) */
 int sodt_transpose_f32(const float* src, float* dst, int rows, int cols, int accumulate, sodt_stream_t st);
+
+/* out[r][c] (f32) += sum_b d[b][r][c]: gradient of the batch-broadcast pos_embed add (backbone_vit.py:215-217) */
+int sodt_batch_sum(const void* d, float* out, int B, long RC, int dtype, sodt_stream_t st);
 
 /* f32 <-> run dtype elementwise cast */
 int sodt_cast(const void* src, void* dst, long n, int src_dtype, int dst_dtype, sodt_stream_t st);

@@ -427,6 +427,9 @@ def state_dict_spec(img_size: int = 512, nc: int = 8) -> Dict[str, Tuple[int, ..
         s[e + f"chan_block.norm{i}.weight"] = (CH_EMBED,)
         s[e + f"chan_block.norm{i}.bias"] = (CH_EMBED,)
     for si, (C, depth, ws) in enumerate(zip(STAGE_DIMS, STAGE_DEPTHS, STAGE_WINDOWS), start=1):
+        res = t >> (si - 1)
+        if res <= ws:          # SwinTransformerBlock ctor clamp (backbone_vit.py:1042-1045)
+            ws = res
         for i in range(depth):
             p = e + f"stage{si}.{i}."
             linear = (SHIFTS[i] == 0) or si == 3

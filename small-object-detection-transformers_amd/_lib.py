@@ -81,6 +81,8 @@ SIGNATURES = {
     "sodt_prep_weights": [_P, _I, _I, _I, _P],
     "sodt_transpose_f32": [_P, _P, _I, _I, _I, _P],
     "sodt_cast": [_P, _P, _L, _I, _I, _P],
+    "sodt_batch_sum": [_P, _P, _I, _L, _I, _P],
+    "sodt_memset_zero": [_P, _L, _P],
 }
 
 _lib = None

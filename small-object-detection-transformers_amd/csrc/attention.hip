@@ -263,12 +263,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_dq_finish_kernel(const float* __restrict__ acc, T* __restrict__ dqkv,
+__global__ __launch_bounds__(256) void attn_dq_finish_kernel(float* __restrict__ acc, T* __restrict__ dqkv,
                                                             long M, int C) {
   const long total = M * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long tok = i / C; const int c = (int)(i - tok * C);
     dqkv[tok * 3 * C + c] = from_f<T>(acc[i]);
+    acc[i] = 0.f;   // the accumulator is left zeroed for the next call
   }
 }
 

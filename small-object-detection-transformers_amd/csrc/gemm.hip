@@ -479,7 +479,7 @@ extern "C" int sodt_gemm_tn(const sodt_gemm_tn_args* g, int dtype, sodt_stream_t
   if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->splits < 1 || !g->dW || !g->dY) return SODT_EINVAL;
   const int kpl = dtype == SODT_BF16 ? 8 : 4;
   if (!aspec_ok(g->x, g->K, kpl)) return SODT_EINVAL;
-  if ((g->ldy % kpl) || (g->N % kpl) || (((uintptr_t)g->dY) & 15)) return SODT_EINVAL;
+  if ((g->ldy % kpl) || g->ldy < (g->N + kpl - 1) / kpl * kpl || (((uintptr_t)g->dY) & 15)) return SODT_EINVAL;
   if (g->kperm_t > 1 && (g->kperm_c <= 0 || g->kperm_c * g->kperm_t != g->K)) return SODT_EINVAL;
   const int tiles = ((g->N + 127) / 128) * ((g->K + 127) / 128);
   dim3 grid(tiles, g->splits), block(256);

@@ -241,12 +241,23 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
     const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
     if (accumulate) dst[(long)c * rows + r] += src[i];
     else dst[(long)c * rows + r] = src[i];
+    if (accumulate == 2) const_cast<float*>(src)[i] = 0.f;
   }
 }
 
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) d[i] = from_f<D>(to_f(s[i]));
+}
+
+// out[r][c] (f32) += sum_b d[b][r][c]   (pos_embed gradient: backbone_vit.py:215-217 backward)
+template <typename T>
+__global__ __launch_bounds__(256) void batch_sum_kernel(const T* __restrict__ d, float* __restrict__ out, int B, long RC) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < RC; i += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += to_f(d[(long)b * RC + i]);
+    out[i] += s;
+  }
 }
 
 inline unsigned nblocks(long work, int cap = 4096) {
@@ -373,6 +384,20 @@ extern "C" int sodt_cast(const void* src, void* dst, long n, int src_dtype, int 
   else if (src_dtype == SODT_F32 && dst_dtype == SODT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(gr), dim3(256), 0, (hipStream_t)st, (const float*)src, (float*)dst, n);
   else return SODT_EINVAL;
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+extern "C" int sodt_batch_sum(const void* d, float* out, int B, long RC, int dtype, sodt_stream_t st) {
+  if (!d || !out || B <= 0 || RC <= 0) return SODT_EINVAL;
+  const unsigned gr = nblocks(RC);
+  if (dtype == SODT_BF16) hipLaunchKernelGGL(batch_sum_kernel<bf16>, dim3(gr), dim3(256), 0, (hipStream_t)st, (const bf16*)d, out, B, RC);
+  else if (dtype == SODT_F32) hipLaunchKernelGGL(batch_sum_kernel<float>, dim3(gr), dim3(256), 0, (hipStream_t)st, (const float*)d, out, B, RC);
+  else return SODT_EINVAL;
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+extern "C" int sodt_memset_zero(void* p, long bytes, sodt_stream_t st) {
+  if (!p || bytes <= 0) return SODT_EINVAL;
+  return hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)st) == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
 extern "C" const char* sodt_version(void) { return "sodt_hip 0.1 (gfx950)"; }

@@ -1,0 +1,612 @@
+"""Execution engine: the whole forward AND backward of Model(model.yaml) as a fixed
+sequence of HIP kernels (C ABI, include/sodt_hip.h), token-major activations.
+
+* One ``Plan`` per (batch, resolution, dtype, mode): every activation / gradient buffer
+  is allocated once; the first run records every launch, later runs replay the list.
+* Backward is hand-written (no torch autograd inside): ``_EngineFn`` is a single
+  autograd node whose backward runs the recorded reverse sequence and deposits parameter
+  gradients into one flat f32 buffer (``param.grad`` are views of it), the layout a
+  bucketed RCCL all-reduce wants (ddp.py).
+* Reference lines each phase replaces are cited in the kernel sources and
+  include/sodt_hip.h; the graph is backbone_vit.py:190-272 + models/model.yaml:65-74.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import SegSpec
+
+HEADS = 12
+E = "image_encoder."
+TAPS2 = ((0, 0), (0, 1), (1, 0), (1, 1))                       # (dy, dx) of the 2x2 conv, kernel index kh*2+kw
+TAPS3 = tuple((dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1))
+MERGE = ((0, 0), (1, 0), (0, 1), (1, 1))                        # PatchMerging gather order (backbone_vit.py:850-853)
+
+
+class Plan:
+    def __init__(self, B, S, dt, training, dev):
+        self.B, self.S, self.dt, self.training, self.dev = B, S, dt, training, dev
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.fwd_pre: Optional[list] = None
+        self.fwd_main: Optional[list] = None
+        self.bwd_main: Optional[list] = None
+        self.saved: dict = {}
+
+    def buf(self, name, shape, dtype=None, zero=False):
+        t = self.bufs.get(name)
+        if t is None:
+            dtype = self.dt if dtype is None else dtype
+            t = (torch.zeros if zero else torch.empty)(shape, device=self.dev, dtype=dtype)
+            self.bufs[name] = t
+        return t
+
+
+class _EngineFn(torch.autograd.Function):
+    """One autograd node for the whole model.  Parameter gradients are written straight into
+    ``param.grad`` (views of the engine's flat buffer), so the node returns None for them."""
+
+    @staticmethod
+    def forward(ctx, engine, plan, x_rgb, x_ir, anchor):
+        ctx.engine, ctx.plan = engine, plan
+        ctx.inputs = (x_rgb, x_ir)
+        pred = engine._forward(plan, x_rgb, x_ir)
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        ctx.engine._backward(ctx.plan, ctx.inputs[0], ctx.inputs[1], dpred.contiguous().float())
+        return None, None, None, None, None
+
+
+class Engine:
+    def __init__(self, model):
+        self.model = model
+        self.params: Dict[str, torch.nn.Parameter] = dict(model.named_parameters())
+        self.buffers: Dict[str, torch.Tensor] = dict(model.named_buffers())
+        p0 = next(iter(self.params.values()))
+        if not p0.is_cuda:
+            raise RuntimeError("move the model to the GPU first: the engine has no CPU path")
+        for n, p in self.params.items():
+            if p.dtype != torch.float32:
+                raise RuntimeError(f"master parameters must be float32 (got {p.dtype} for {n}); call model.float()")
+        self.dev = p0.device
+        enc = model.image_encoder
+        self.img_t = enc.pos_embed.shape[1]
+        det = model.detect[-1]
+        self.na, self.no, self.nc = det.na, det.no, det.nc
+        self.fused = not hasattr(model.detect[0], "bn")
+        self._check_head()
+        self.plans: Dict[Tuple, Plan] = {}
+        self.prep: Dict[torch.dtype, dict] = {}
+        self._build_grad_buffer()
+        # anchor that makes the autograd node require grad even if the caller froze everything else
+        self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
+        self.ddp = None     # set by ddp.attach()
+
+    # ------------------------------------------------------------------ structure checks
+    def _check_head(self):
+        from . import model as M
+        kinds = [type(m).__name__ for m in self.model.detect]
+        want = ["Conv", "Upsample", "Concat", "C3", "Conv", "Upsample", "Concat", "C3", "Detect"]
+        if kinds != want:
+            raise NotImplementedError(f"head graph {kinds} is not models/model.yaml:65-74 ({want})")
+        d = self.model.detect
+        if d[2].f != [-1, 1] or d[6].f != [-1, 0] or d[0].f != 2 or d[8].f != [10]:
+            raise NotImplementedError("head wiring differs from models/model.yaml:65-74")
+        for c3 in (d[3], d[7]):
+            if len(c3.m) != 1 or c3.m[0].add:
+                raise NotImplementedError("C3 with n=1, shortcut=False only (models/model.yaml:68,73)")
+        assert isinstance(d[8], M.Detect) and d[8].nl == 1
+
+    # ------------------------------------------------------------------ gradients: one flat f32 buffer
+    def _build_grad_buffer(self):
+        order = [E + f"channel_embed_{c}.proj.weight" for c in "rgbi"] + [E + f"channel_embed_{c}.proj.bias" for c in "rgbi"]
+        order += [E + f"chan_block.norm{i}.weight" for i in range(1, 5)] + [E + f"chan_block.norm{i}.bias" for i in range(1, 5)]
+        rest = [n for n in self.params if n not in set(order)]
+        self.grad_order = order + rest
+        offs, tot = {}, 0
+        for n in self.grad_order:
+            offs[n] = tot
+            tot += (self.params[n].numel() + 3) // 4 * 4      # keep every view 16-byte aligned
+        self.flat_grad = torch.zeros(tot, device=self.dev, dtype=torch.float32)
+        self.g: Dict[str, torch.Tensor] = {}
+        for n in self.grad_order:
+            p = self.params[n]
+            self.g[n] = self.flat_grad[offs[n]: offs[n] + p.numel()].view(p.shape)
+        self.grad_offsets = offs
+        fe = offs[E + "channel_embed_r.proj.weight"]
+        self.g_fe_w = self.flat_grad[fe: fe + 4 * 48 * 16]
+        self.g_fe_b = self.flat_grad[offs[E + "channel_embed_r.proj.bias"]:][: 4 * 48]
+        self.g_fe_g = self.flat_grad[offs[E + "chan_block.norm1.weight"]:][: 4 * 48]
+        self.g_fe_be = self.flat_grad[offs[E + "chan_block.norm1.bias"]:][: 4 * 48]
+
+    def _claim_grads(self):
+        """Make param.grad the views of the flat buffer; zero it when the grads were reset."""
+        fresh = False
+        for n, p in self.params.items():
+            v = self.g[n]
+            if p.grad is None:
+                p.grad = v
+                fresh = True
+            elif p.grad.data_ptr() != v.data_ptr():
+                raise RuntimeError(f"{n}.grad is not the engine's flat-buffer view; use optimizer.zero_grad(set_to_none=True) "
+                                   "or leave .grad untouched between steps")
+        return fresh
+
+    # ------------------------------------------------------------------ prepared parameters
+    def _prep_for(self, dt):
+        P = self.prep.get(dt)
+        if P is not None:
+            return P
+        dev = self.dev
+        w: Dict[str, torch.Tensor] = {}
+        wT: Dict[str, torch.Tensor] = {}
+        descs_t, descs_f = [], []
+
+        def add(desc_list, src, dst, dims, perm, dst_ld):
+            d = L.PrepDesc()
+            d.src, d.dst = src.data_ptr(), dst.data_ptr()
+            d.d0, d.d1, d.d2 = dims
+            d.p0, d.p1, d.p2 = perm
+            d.dst_ld = dst_ld
+            desc_list.append(d)
+
+        for n, p in self.params.items():
+            if p.dim() < 2 or "relative_position_bias_table" in n or "channel_embed" in n:
+                continue
+            if n == E + "pos_embed":
+                t = p.shape[1]
+                w[n] = torch.zeros(t * t, 192, device=dev, dtype=dt)
+                add(descs_t, p, w[n], (t * t, 192, 1), (0, 1, 2), 192)
+                continue
+            N, K = p.shape[0], p.shape[1]
+            taps = p.numel() // (N * K)
+            Np = (N + 15) // 16 * 16 if n.startswith("detect.8.") else N     # Detect: 39 -> 48 zero-padded
+            w[n] = torch.zeros(Np, taps * K, device=dev, dtype=dt)           # [N][tap*K + k]
+            add(descs_t, p, w[n], (N, K, taps), (0, 2, 1), taps * K)
+            wT[n] = torch.zeros(K, taps * Np, device=dev, dtype=dt)          # [K][tap*N + n]
+            add(descs_t, p, wT[n], (N, K, taps), (1, 2, 0), taps * Np)
+        # f32 side: transposed relative-position tables, packed front-end parameters
+        bias_t: Dict[str, torch.Tensor] = {}
+        for n, p in self.params.items():
+            if "relative_position_bias_table" in n:
+                bias_t[n] = torch.zeros(p.shape[1], p.shape[0], device=dev, dtype=torch.float32)
+                add(descs_f, p, bias_t[n], (p.shape[0], p.shape[1], 1), (1, 0, 2), p.shape[0])
+        fe = {k: torch.zeros(4 * 48 * (16 if k == "w" else 1), device=dev, dtype=torch.float32) for k in ("w", "b", "g", "be")}
+        for ci, c in enumerate("rgbi"):
+            add(descs_f, self.params[E + f"channel_embed_{c}.proj.weight"], fe["w"][ci * 768:], (48, 16, 1), (0, 1, 2), 16)
+            add(descs_f, self.params[E + f"channel_embed_{c}.proj.bias"], fe["b"][ci * 48:], (48, 1, 1), (0, 1, 2), 1)
+            add(descs_f, self.params[E + f"chan_block.norm{ci + 1}.weight"], fe["g"][ci * 48:], (48, 1, 1), (0, 1, 2), 1)
+            add(descs_f, self.params[E + f"chan_block.norm{ci + 1}.bias"], fe["be"][ci * 48:], (48, 1, 1), (0, 1, 2), 1)
+
+        def table(descs):
+            arr = (L.PrepDesc * len(descs))(*descs)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            mx = max(d.d0 * d.d1 * d.d2 for d in descs)
+            return host.to(dev), len(descs), mx
+        P = dict(w=w, wT=wT, bias_t=bias_t, fe=fe, tab_t=table(descs_t), tab_f=table(descs_f), dt=dt,
+                 ones={}, keep=(descs_t, descs_f))
+        self.prep[dt] = P
+        return P
+
+    def _run_prep(self, P):
+        tt, nt, mt = P["tab_t"]
+        ops.prep_weights(tt, nt, mt, L.BF16 if P["dt"] == torch.bfloat16 else L.F32)
+        tf, nf, mf = P["tab_f"]
+        ops.prep_weights(tf, nf, mf, L.F32)
+
+    # ------------------------------------------------------------------ public entry
+    def run(self, x_rgb, x_ir, dt, training):
+        if x_rgb.dim() != 4 or x_rgb.shape[1] != 3 or x_ir.dim() != 4 or x_rgb.shape[-1] != x_rgb.shape[-2]:
+            raise ValueError("expected x_rgb (B,3,S,S) and x_ir (B,>=1,S,S)")
+        B, _, S, _ = x_rgb.shape
+        if S % 32:
+            raise ValueError("S must be a multiple of 32 (4x patch stride, 8x8 windows on t/2 .. even t/4)")
+        x_rgb = x_rgb.float().contiguous()
+        x_ir = x_ir.float().contiguous()
+        key = (B, S, dt, training)
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = self.plans[key] = Plan(B, S, dt, training, self.dev)
+        if training and torch.is_grad_enabled():
+            pred = _EngineFn.apply(self, plan, x_rgb, x_ir, self._anchor)
+        else:
+            pred = self._forward(plan, x_rgb, x_ir)
+        return pred, self._features(plan)
+
+    def decode(self, pred):
+        B, na, ny, nx, no = pred.shape
+        z = torch.empty(B, na * ny * nx, no, device=pred.device, dtype=torch.float32)
+        ag = self.buffers["detect.8.anchor_grid"].reshape(-1).contiguous().float()
+        ops.detect_decode(pred, ag, z, B, na, ny, nx, no, 4.0)
+        return z
+
+    def _features(self, plan):
+        """y[0..10] of forward_once (model.py:246,281) as NCHW *views* of the workspace (valid until the
+        next forward).  y4,y5,y8,y9 (upsample / concat) are never materialised by the kernels; they are
+        built with torch only when model.materialize_features is set."""
+        B, t = plan.B, plan.S // 4
+        b = plan.bufs
+
+        def nchw(name, h, c):
+            return b[name].view(B, h, h, c).permute(0, 3, 1, 2)
+        y = [nchw("f0", t, 256), nchw("f1", t // 2, 256), nchw("f2", t // 4, 512), nchw("h0.y", t // 4, 256), None, None,
+             nchw("h3.cv3.y", t // 2, 256), nchw("h4.y", t // 2, 128), None, None, nchw("h7.cv3.y", t, 128)]
+        if self.model.materialize_features:
+            import torch.nn.functional as F
+            y[4] = F.interpolate(y[3].float(), scale_factor=2, mode="nearest")
+            y[5] = torch.cat((y[4], y[1].float()), 1)
+            y[8] = F.interpolate(y[7].float(), scale_factor=2, mode="nearest")
+            y[9] = torch.cat((y[8], y[0].float()), 1)
+        return y
+
+    # ================================================================== forward
+    def _forward(self, plan: Plan, x_rgb, x_ir):
+        P = self._prep_for(plan.dt)
+        B, S = plan.B, plan.S
+        t = S // 4
+        # (1) parameter preparation (recorded)
+        if plan.fwd_pre is None:
+            with ops.Recorder() as rec:
+                self._run_prep(P)
+            plan.fwd_pre = rec.calls
+        else:
+            ops.replay(plan.fwd_pre)
+        # (2) front end: live call (input pointers change per step)
+        x0 = plan.buf("x0", (B * t * t, 192))
+        fe = P["fe"]
+        ops.frontend_fwd(x_rgb, x_ir, x_ir.shape[1] * S * S, fe["w"], fe["b"], fe["g"], fe["be"], x0, B, S, 1)
+        # (3) encoder + head (recorded)
+        if plan.fwd_main is None:
+            with ops.Recorder() as rec:
+                self._forward_main(plan, P)
+            plan.fwd_main = rec.calls
+        else:
+            ops.replay(plan.fwd_main)
+        # (4) Detect: live (fresh output tensor every call)
+        T1 = B * t * t
+        pred = torch.empty(B, self.na, t, t, self.no, device=self.dev, dtype=torch.float32)
+        ops.gemm_nt([SegSpec(plan.bufs["h7.cv3.y"])], P["w"]["detect.8.m.0.weight"], pred, T1, self.na * self.no, 128,
+                    bias=self.params["detect.8.m.0.bias"], detect=(self.na, self.no, t * t))
+        return pred
+
+    def _forward_main(self, plan: Plan, P):
+        B, S = plan.B, plan.S
+        t = S // 4
+        p, w = self.params, P["w"]
+        T1 = B * t * t
+        x0 = plan.bufs["x0"]
+        # 1x1 token-mixing conv + bias + pos_embed (only when t matches: backbone_vit.py:215-217)
+        x = plan.buf("xe", (T1, 192))
+        use_pos = (t == self.img_t)
+        plan.saved["use_pos"] = use_pos
+        ops.gemm_nt([SegSpec(x0)], w[E + "patch_embed.proj.weight"], x, T1, 192, 192, bias=p[E + "patch_embed.proj.bias"],
+                    resid=w[E + "pos_embed"] if use_pos else None, rmod=t * t if use_pos else 0)
+        enc = self.model.image_encoder
+        outs = {}
+        H = t
+        for i, blk in enumerate(enc.stage1):
+            x = self._block_fwd(plan, P, f"stage1.{i}", blk, x, B, H, H)
+            outs[i] = x
+        f0 = plan.buf("f0", (T1, 256))
+        ops.gemm_nt([SegSpec(outs[4]), SegSpec(outs[5])], w[E + "neck1.weight"], f0, T1, 256, 384)
+        x = self._merge_fwd(plan, P, "pmerging1", x, B, H, H, 192)
+        H //= 2
+        for i, blk in enumerate(enc.stage2):
+            x = self._block_fwd(plan, P, f"stage2.{i}", blk, x, B, H, H)
+        T2 = B * H * H
+        f1 = plan.buf("f1", (T2, 256))
+        ops.gemm_nt([SegSpec(x)], w[E + "neck2.weight"], f1, T2, 256, 384)
+        x = self._merge_fwd(plan, P, "pmerging2", x, B, H, H, 384)
+        H //= 2
+        for i, blk in enumerate(enc.stage3):
+            x = self._block_fwd(plan, P, f"stage3.{i}", blk, x, B, H, H)
+        T3 = B * H * H
+        f2 = plan.buf("f2", (T3, 512))
+        ops.gemm_nt([SegSpec(x)], w[E + "neck3.weight"], f2, T3, 512, 768)
+        # ---- head (models/model.yaml:65-74), token-major
+        h4, h2 = t // 4, t // 2
+        y3 = self._conv_fwd(plan, P, "h0", "detect.0.", [SegSpec(f2)], None, T3, 512, 256, 1)
+        segs = [SegSpec(y3, 256, 0, 0, 0, 1, 1, h4, h4), SegSpec(f1, 256, 0, 0, 0, 1, 0, h2, h2)]
+        y6 = self._c3_fwd(plan, P, "h3", "detect.3.", segs, (h2, h2), T2, 512, 256)
+        y7 = self._conv_fwd(plan, P, "h4", "detect.4.", [SegSpec(y6)], None, T2, 256, 128, 1)
+        segs = [SegSpec(y7, 128, 0, 0, 0, 1, 1, h2, h2), SegSpec(f0, 256, 0, 0, 0, 1, 0, t, t)]
+        self._c3_fwd(plan, P, "h7", "detect.7.", segs, (t, t), T1, 384, 128)
+
+    # ------------------------------------------------------------------ Swin block
+    def _block_geo(self, blk, H, W):
+        ws, shift = blk.window_size, blk.shift_size
+        if min(H, W) <= ws:
+            ws, shift = min(H, W), 0
+        L2 = 2 * ws - 1
+        if blk.attn.relative_position_bias_table.shape[0] != L2 * L2:
+            raise ValueError(f"input resolution gives a {ws}x{ws} window but the model was built with a "
+                             f"{blk.attn.window_size[0]}-window bias table; build Model with the matching img_size")
+        return ws, shift
+
+    def _block_fwd(self, plan, P, tag, blk, x_in, B, H, W):
+        p, w = self.params, P["w"]
+        pre = E + tag + "."
+        Cc = blk.dim
+        M = B * H * W
+        ws, shift = self._block_geo(blk, H, W)
+        xn1 = plan.buf(tag + ".xn1", (M, Cc))
+        st1 = plan.buf(tag + ".st1", (M, 2), torch.float32)
+        ops.layernorm_fwd(x_in, p[pre + "norm1.weight"], p[pre + "norm1.bias"], xn1, st1, M, Cc)
+        qkv = plan.buf(tag + ".qkv", (M, 3 * Cc))
+        ops.gemm_nt([SegSpec(xn1)], w[pre + "attn.qkv.weight"], qkv, M, 3 * Cc, Cc, bias=p[pre + "attn.qkv.bias"])
+        ao = plan.buf(tag + ".ao", (M, Cc))
+        lse = plan.buf(tag + ".lse", (M, HEADS), torch.float32)
+        ops.window_attn_fwd(qkv, P["bias_t"][pre + "attn.relative_position_bias_table"], ao, lse, B, H, W, Cc, HEADS, ws, shift)
+        xm = plan.buf(tag + ".xm", (M, Cc))
+        ops.gemm_nt([SegSpec(ao)], w[pre + "attn.proj.weight"], xm, M, Cc, Cc, bias=p[pre + "attn.proj.bias"], resid=x_in)
+        xn2 = plan.buf(tag + ".xn2", (M, Cc))
+        st2 = plan.buf(tag + ".st2", (M, 2), torch.float32)
+        ops.layernorm_fwd(xm, p[pre + "norm2.weight"], p[pre + "norm2.bias"], xn2, st2, M, Cc)
+        xo = plan.buf(tag + ".xo", (M, Cc))
+        if blk.mlp.linear:
+            hp = plan.buf(tag + ".hp", (M, 4 * Cc))
+            ha = plan.buf(tag + ".ha", (M, 4 * Cc))
+            ops.gemm_nt([SegSpec(xn2)], w[pre + "mlp.fc1.weight"], hp, M, 4 * Cc, Cc, bias=p[pre + "mlp.fc1.bias"], gelu_out=ha)
+            ops.gemm_nt([SegSpec(ha)], w[pre + "mlp.fc2.weight"], xo, M, Cc, 4 * Cc, bias=p[pre + "mlp.fc2.bias"], resid=xm)
+        else:
+            u = plan.buf(tag + ".u", (M, Cc))
+            ops.gemm_nt([SegSpec(xn2)], w[pre + "mlp.fc1.weight"], u, M, Cc, Cc, bias=p[pre + "mlp.fc1.bias"])
+            cp = plan.buf(tag + ".cp", (M, Cc))
+            ca = plan.buf(tag + ".ca", (M, Cc))
+            segs = [SegSpec(u, Cc, 0, dy, dx, 1, 0, H, W) for (dy, dx) in TAPS2]
+            ops.gemm_nt(segs, w[pre + "mlp.conv1.weight"], cp, M, Cc, 4 * Cc, spatial=(H, W), bias=p[pre + "mlp.conv1.bias"],
+                        gelu_out=ca)
+            ops.gemm_nt([SegSpec(ca)], w[pre + "mlp.fc2.weight"], xo, M, Cc, Cc, bias=p[pre + "mlp.fc2.bias"], resid=xm)
+        plan.saved[tag] = dict(x_in=x_in, geo=(B, H, W, Cc, ws, shift))
+        return xo
+
+    def _block_bwd(self, plan, P, tag, blk, dY, dX):
+        """dY: gradient wrt the block output; writes the gradient wrt the block input into dX."""
+        p, wT, g, b = self.params, P["wT"], self.g, plan.bufs
+        pre = E + tag + "."
+        sv = plan.saved[tag]
+        B, H, W, Cc, ws, shift = sv["geo"]
+        M = B * H * W
+        x_in = sv["x_in"]
+        xm, xn2, xn1, ao, qkv = b[tag + ".xm"], b[tag + ".xn2"], b[tag + ".xn1"], b[tag + ".ao"], b[tag + ".qkv"]
+        dxn = plan.buf(f"g.dxn.{Cc}", (M, Cc))
+        dxm = plan.buf(f"g.dxm.{Cc}", (M, Cc))
+        if blk.mlp.linear:
+            hp, ha = b[tag + ".hp"], b[tag + ".ha"]
+            dh = plan.buf(f"g.dh.{Cc}", (M, 4 * Cc))
+            ops.gemm_tn(dY, [SegSpec(ha)], g[pre + "mlp.fc2.weight"], M, Cc, 4 * Cc, dbias=g[pre + "mlp.fc2.bias"])
+            ops.gemm_nt([SegSpec(dY)], wT[pre + "mlp.fc2.weight"], dh, M, 4 * Cc, Cc, dgelu_aux=hp)
+            ops.gemm_tn(dh, [SegSpec(xn2)], g[pre + "mlp.fc1.weight"], M, 4 * Cc, Cc, dbias=g[pre + "mlp.fc1.bias"])
+            ops.gemm_nt([SegSpec(dh)], wT[pre + "mlp.fc1.weight"], dxn, M, Cc, 4 * Cc)
+        else:
+            u, cp, ca = b[tag + ".u"], b[tag + ".cp"], b[tag + ".ca"]
+            dc = plan.buf(f"g.dc.{Cc}", (M, Cc))
+            du = plan.buf(f"g.du.{Cc}", (M, Cc))
+            ops.gemm_tn(dY, [SegSpec(ca)], g[pre + "mlp.fc2.weight"], M, Cc, Cc, dbias=g[pre + "mlp.fc2.bias"])
+            ops.gemm_nt([SegSpec(dY)], wT[pre + "mlp.fc2.weight"], dc, M, Cc, Cc, dgelu_aux=cp)
+            segs = [SegSpec(u, Cc, 0, dy, dx, 1, 0, H, W) for (dy, dx) in TAPS2]
+            ops.gemm_tn(dc, segs, g[pre + "mlp.conv1.weight"], M, Cc, 4 * Cc, spatial=(H, W), dbias=g[pre + "mlp.conv1.bias"],
+                        kperm=(Cc, 4))
+            segs = [SegSpec(dc, Cc, 0, -dy, -dx, 1, 0, H, W) for (dy, dx) in TAPS2]
+            ops.gemm_nt(segs, wT[pre + "mlp.conv1.weight"], du, M, Cc, 4 * Cc, spatial=(H, W))
+            ops.gemm_tn(du, [SegSpec(xn2)], g[pre + "mlp.fc1.weight"], M, Cc, Cc, dbias=g[pre + "mlp.fc1.bias"])
+            ops.gemm_nt([SegSpec(du)], wT[pre + "mlp.fc1.weight"], dxn, M, Cc, Cc)
+        ops.layernorm_bwd(dxn, xm, b[tag + ".st2"], p[pre + "norm2.weight"], dY, dxm, g[pre + "norm2.weight"], g[pre + "norm2.bias"], M, Cc)
+        # attention
+        ops.gemm_tn(dxm, [SegSpec(ao)], g[pre + "attn.proj.weight"], M, Cc, Cc, dbias=g[pre + "attn.proj.bias"])
+        dao = dxn
+        ops.gemm_nt([SegSpec(dxm)], wT[pre + "attn.proj.weight"], dao, M, Cc, Cc)
+        dqkv = plan.buf(f"g.dqkv.{Cc}", (M, 3 * Cc))
+        L2 = 2 * ws - 1
+        dbt = plan.buf(f"g.dbt.{L2}", (HEADS, L2 * L2), torch.float32, zero=True)
+        scratch = plan.buf(f"g.attn_scratch.{Cc}", (M * (Cc + HEADS),), torch.float32, zero=True) if ws * ws > 64 else None
+        ops.window_attn_bwd(qkv, P["bias_t"][pre + "attn.relative_position_bias_table"], ao, dao, b[tag + ".lse"], dqkv, dbt,
+                            scratch, B, H, W, Cc, HEADS, ws, shift)
+        ops.transpose_f32(dbt, g[pre + "attn.relative_position_bias_table"], HEADS, L2 * L2, accumulate=2)
+        ops.gemm_tn(dqkv, [SegSpec(xn1)], g[pre + "attn.qkv.weight"], M, 3 * Cc, Cc, dbias=g[pre + "attn.qkv.bias"])
+        ops.gemm_nt([SegSpec(dqkv)], wT[pre + "attn.qkv.weight"], dxn, M, Cc, 3 * Cc)
+        ops.layernorm_bwd(dxn, x_in, b[tag + ".st1"], p[pre + "norm1.weight"], dxm, dX, g[pre + "norm1.weight"], g[pre + "norm1.bias"], M, Cc)
+
+    # ------------------------------------------------------------------ PatchMerging
+    def _merge_fwd(self, plan, P, tag, x, B, H, W, Cc):
+        p, w = self.params, P["w"]
+        pre = E + tag + "."
+        M2 = B * (H // 2) * (W // 2)
+        z = plan.buf(tag + ".z", (M2, 2 * Cc))
+        segs = [SegSpec(x, Cc, 0, dy, dx, 2, 0, H, W) for (dy, dx) in MERGE]
+        ops.gemm_nt(segs, w[pre + "reduction.weight"], z, M2, 2 * Cc, 4 * Cc, spatial=(H // 2, W // 2))
+        y = plan.buf(tag + ".y", (M2, 2 * Cc))
+        st = plan.buf(tag + ".st", (M2, 2), torch.float32)
+        ops.layernorm_fwd(z, p[pre + "norm.weight"], p[pre + "norm.bias"], y, st, M2, 2 * Cc)
+        plan.saved[tag] = dict(x=x, geo=(B, H, W, Cc))
+        return y
+
+    def _merge_bwd(self, plan, P, tag, dY, dX):
+        p, wT, g, b = self.params, P["wT"], self.g, plan.bufs
+        pre = E + tag + "."
+        sv = plan.saved[tag]
+        B, H, W, Cc = sv["geo"]
+        M2 = B * (H // 2) * (W // 2)
+        dz = plan.buf(tag + ".dz", (M2, 2 * Cc))
+        ops.layernorm_bwd(dY, b[tag + ".z"], b[tag + ".st"], p[pre + "norm.weight"], None, dz, g[pre + "norm.weight"],
+                          g[pre + "norm.bias"], M2, 2 * Cc)
+        segs = [SegSpec(sv["x"], Cc, 0, dy, dx, 2, 0, H, W) for (dy, dx) in MERGE]
+        ops.gemm_tn(dz, segs, g[pre + "reduction.weight"], M2, 2 * Cc, 4 * Cc, spatial=(H // 2, W // 2))
+        for tap, (dy, dx) in enumerate(MERGE):   # the four taps tile the input grid exactly once
+            ops.gemm_nt([SegSpec(dz, 2 * Cc, 0, 0, 0, 1, 0, H // 2, W // 2)], wT[pre + "reduction.weight"], dX, M2, Cc, 2 * Cc,
+                        spatial=(H // 2, W // 2), w_off=tap * Cc * 2 * Cc, oscatter=(2, dy, dx, H, W))
+
+    # ------------------------------------------------------------------ head units
+    def _conv_fwd(self, plan, P, tag, pname, segs, spatial, M, K, Cout, k):
+        """Conv2d(bias=False)+BN+SiLU (common.py:38-50) as GEMM (+f64 column stats) -> finalize -> normalise+SiLU."""
+        p, w, bufs = self.params, P["w"], self.buffers
+        y = plan.buf(tag + ".y", (M, Cout))
+        wname = pname + "conv.weight"
+        if self.fused:
+            ones = P["ones"].setdefault(Cout, torch.ones(Cout, device=self.dev))
+            ops.gemm_nt(segs, w[wname], y, M, Cout, K, spatial=spatial, affine=(ones, p[pname + "conv.bias"]))
+        elif plan.training:
+            z = plan.buf(tag + ".z", (M, Cout))
+            stats = plan.buf(tag + ".stats", (2, Cout), torch.float64)
+            mr = plan.buf(tag + ".mr", (2, Cout), torch.float32)
+            ops.zero_(stats)
+            ops.gemm_nt(segs, w[wname], z, M, Cout, K, spatial=spatial, stats=stats)
+            ops.bn_finalize(stats, mr, bufs[pname + "bn.running_mean"], bufs[pname + "bn.running_var"], M, Cout, 1e-3, 0.03)
+            ops.bn_silu_fwd(z, mr, p[pname + "bn.weight"], p[pname + "bn.bias"], y, Cout, M, Cout)
+        else:
+            mr = plan.buf(tag + ".mr", (2, Cout), torch.float32)
+            sc = plan.buf(tag + ".sc", (2, Cout), torch.float32)
+            ops.bn_finalize(None, mr, bufs[pname + "bn.running_mean"], bufs[pname + "bn.running_var"], M, Cout, 1e-3, 0.03)
+            ops.bn_affine(mr, p[pname + "bn.weight"], p[pname + "bn.bias"], sc[0], sc[1], Cout)
+            ops.gemm_nt(segs, w[wname], y, M, Cout, K, spatial=spatial, affine=(sc[0], sc[1]))
+        plan.saved[tag] = dict(segs=segs, spatial=spatial, M=M, K=K, Cout=Cout, k=k, pname=pname)
+        return y
+
+    def _conv_bwd(self, plan, tag, dy, lddy, dy_off):
+        """BN+SiLU backward and the conv weight gradient; returns dz (gradient at the conv output)."""
+        p, g, b = self.params, self.g, plan.bufs
+        sv = plan.saved[tag]
+        M, K, Cout, k, pname = sv["M"], sv["K"], sv["Cout"], sv["k"], sv["pname"]
+        red = plan.buf(tag + ".red", (2, Cout), torch.float64)
+        dz = plan.buf(tag + ".dz", (M, Cout))
+        ops.zero_(red)
+        ops.bn_silu_bwd_reduce(dy, lddy, b[tag + ".z"], b[tag + ".mr"], p[pname + "bn.weight"], p[pname + "bn.bias"], red, M, Cout,
+                               dy_off=dy_off)
+        ops.bn_silu_bwd_apply(dy, lddy, b[tag + ".z"], b[tag + ".mr"], p[pname + "bn.weight"], p[pname + "bn.bias"], red, dz,
+                              g[pname + "bn.weight"], g[pname + "bn.bias"], M, Cout, dy_off=dy_off)
+        cin = K // (k * k)
+        ops.gemm_tn(dz, sv["segs"], g[pname + "conv.weight"], M, Cout, K, spatial=sv["spatial"],
+                    kperm=(cin, k * k) if k > 1 else None)
+        return dz
+
+    def _c3_fwd(self, plan, P, tag, pname, segs, spatial, M, c1, c2):
+        c_ = c2 // 2
+        H, W = spatial
+        a1 = self._conv_fwd(plan, P, tag + ".cv1", pname + "cv1.", segs, spatial, M, c1, c_, 1)
+        a2 = self._conv_fwd(plan, P, tag + ".m1", pname + "m.0.cv1.", [SegSpec(a1)], None, M, c_, c_, 1)
+        s3 = [SegSpec(a2, c_, 0, dy, dx, 1, 0, H, W) for (dy, dx) in TAPS3]
+        a3 = self._conv_fwd(plan, P, tag + ".m2", pname + "m.0.cv2.", s3, spatial, M, 9 * c_, c_, 3)
+        b1 = self._conv_fwd(plan, P, tag + ".cv2", pname + "cv2.", segs, spatial, M, c1, c_, 1)
+        out = self._conv_fwd(plan, P, tag + ".cv3", pname + "cv3.", [SegSpec(a3), SegSpec(b1)], None, M, 2 * c_, c2, 1)
+        plan.saved[tag] = dict(M=M, c1=c1, c2=c2, spatial=spatial, pname=pname)
+        return out
+
+    def _c3_bwd(self, plan, P, tag, dout, ldd, d_off):
+        """returns d(concatenated input) [M][c1]."""
+        wT = P["wT"]
+        sv = plan.saved[tag]
+        M, c1, c2, (H, W), pname = sv["M"], sv["c1"], sv["c2"], sv["spatial"], sv["pname"]
+        c_ = c2 // 2
+        dz3 = self._conv_bwd(plan, tag + ".cv3", dout, ldd, d_off)
+        dcat = plan.buf(tag + ".dcat", (M, 2 * c_))
+        ops.gemm_nt([SegSpec(dz3)], wT[pname + "cv3.conv.weight"], dcat, M, 2 * c_, c2)
+        din = plan.buf(tag + ".din", (M, c1))
+        dzb = self._conv_bwd(plan, tag + ".cv2", dcat, 2 * c_, c_)
+        ops.gemm_nt([SegSpec(dzb)], wT[pname + "cv2.conv.weight"], din, M, c1, c_)
+        dza3 = self._conv_bwd(plan, tag + ".m2", dcat, 2 * c_, 0)
+        da = plan.buf(tag + ".da", (M, c_))
+        segs = [SegSpec(dza3, c_, 0, -dy, -dx, 1, 0, H, W) for (dy, dx) in TAPS3]
+        ops.gemm_nt(segs, wT[pname + "m.0.cv2.conv.weight"], da, M, c_, 9 * c_, spatial=(H, W))
+        dza2 = self._conv_bwd(plan, tag + ".m1", da, c_, 0)
+        ops.gemm_nt([SegSpec(dza2)], wT[pname + "m.0.cv1.conv.weight"], da, M, c_, c_)
+        dza1 = self._conv_bwd(plan, tag + ".cv1", da, c_, 0)
+        ops.gemm_nt([SegSpec(dza1)], wT[pname + "cv1.conv.weight"], din, M, c1, c_, resid=din)
+        return din
+
+    # ================================================================== backward
+    def _backward(self, plan: Plan, x_rgb, x_ir, dpred):
+        if self.fused or not plan.training:
+            raise RuntimeError("backward needs a training-mode, un-fused model")
+        P = self._prep_for(plan.dt)
+        B, S = plan.B, plan.S
+        t = S // 4
+        T1 = B * t * t
+        if self._claim_grads():
+            ops.zero_(self.flat_grad)
+        # (1) Detect backward: live (dpred pointer changes)
+        dzd = plan.buf("g.dzd", (T1, 48))
+        ops.detect_unpermute(dpred, dzd, 48, B, t * t, self.na, self.no)
+        if plan.bwd_main is None:
+            with ops.Recorder() as rec:
+                self._backward_main(plan, P)
+            plan.bwd_main = rec.calls
+        else:
+            ops.replay(plan.bwd_main)
+        # (3) front end: live
+        fe = P["fe"]
+        ops.frontend_bwd(x_rgb, x_ir, x_ir.shape[1] * S * S, fe["w"], fe["b"], fe["g"], fe["be"], plan.bufs["g.dx0"],
+                         self.g_fe_w, self.g_fe_b, self.g_fe_g, self.g_fe_be, B, S, 1)
+        if self.ddp is not None:
+            self.ddp.reduce(self.flat_grad)
+
+    def _backward_main(self, plan: Plan, P):
+        B, S = plan.B, plan.S
+        t = S // 4
+        wT, g, b = P["wT"], self.g, plan.bufs
+        enc = self.model.image_encoder
+        T1, T2, T3 = B * t * t, B * (t // 2) ** 2, B * (t // 4) ** 2
+        h2, h4 = t // 2, t // 4
+        # ---- Detect
+        dzd = b["g.dzd"]
+        y10 = b["h7.cv3.y"]
+        ops.gemm_tn(dzd, [SegSpec(y10)], g["detect.8.m.0.weight"], T1, self.na * self.no, 128, ldy=48, lddw=128,
+                    dbias=g["detect.8.m.0.bias"])
+        dy10 = plan.buf("g.dy10", (T1, 128))
+        ops.gemm_nt([SegSpec(dzd)], wT["detect.8.m.0.weight"], dy10, T1, 128, 48)
+        # ---- C3 #2 on cat(up(y7), f0)
+        din7 = self._c3_bwd(plan, P, "h7", dy10, 128, 0)                     # [T1][384] = [d up(y7) 128 | d f0 256]
+        dy7 = plan.buf("g.dy7", (T2, 128))
+        ops.gather_sum_rows(din7, 384, dy7, 128, B, h2, h2, 1, 128)
+        dz4 = self._conv_bwd(plan, "h4", dy7, 128, 0)
+        dy6 = plan.buf("g.dy6", (T2, 256))
+        ops.gemm_nt([SegSpec(dz4)], wT["detect.4.conv.weight"], dy6, T2, 256, 128)
+        din3 = self._c3_bwd(plan, P, "h3", dy6, 256, 0)                      # [T2][512] = [d up(y3) 256 | d f1 256]
+        dy3 = plan.buf("g.dy3", (T3, 256))
+        ops.gather_sum_rows(din3, 512, dy3, 256, B, h4, h4, 1, 256)
+        dz0 = self._conv_bwd(plan, "h0", dy3, 256, 0)
+        df2 = plan.buf("g.df2", (T3, 512))
+        ops.gemm_nt([SegSpec(dz0)], wT["detect.0.conv.weight"], df2, T3, 512, 256)
+        # ---- neck3 + stage 3
+        s3out = b["stage3.0.xo"]
+        ops.gemm_tn(df2, [SegSpec(s3out)], g[E + "neck3.weight"], T3, 512, 768)
+        d3a = plan.buf("g.dA.768", (T3, 768))
+        d3b = plan.buf("g.dB.768", (T3, 768))
+        ops.gemm_nt([SegSpec(df2)], wT[E + "neck3.weight"], d3a, T3, 768, 512)
+        self._block_bwd(plan, P, "stage3.0", enc.stage3[0], d3a, d3b)
+        # ---- pmerging2 -> d(stage2 out) ; + neck2
+        dA = plan.buf("g.dA.384", (T2, 384))
+        dB = plan.buf("g.dB.384", (T2, 384))
+        self._merge_bwd(plan, P, "pmerging2", d3b, dA)
+        s2out = b["stage2.3.xo"]
+        ops.gemm_tn(din3, [SegSpec(s2out)], g[E + "neck2.weight"], T2, 256, 384, ldy=512, y_off=256)
+        ops.gemm_nt([SegSpec(din3, 256, 256)], wT[E + "neck2.weight"], dA, T2, 384, 256, resid=dA)
+        cur, other = dA, dB
+        for i in reversed(range(4)):
+            self._block_bwd(plan, P, f"stage2.{i}", enc.stage2[i], cur, other)
+            cur, other = other, cur
+        # ---- pmerging1 -> d(stage1 out5) ; + neck1
+        dA = plan.buf("g.dA.192", (T1, 192))
+        dB = plan.buf("g.dB.192", (T1, 192))
+        self._merge_bwd(plan, P, "pmerging1", cur, dA)
+        o4, o5 = b["stage1.4.xo"], b["stage1.5.xo"]
+        ops.gemm_tn(din7, [SegSpec(o4), SegSpec(o5)], g[E + "neck1.weight"], T1, 256, 384, ldy=384, y_off=128)
+        df0 = SegSpec(din7, 256, 128)
+        ops.gemm_nt([df0], wT[E + "neck1.weight"], dA, T1, 192, 256, w_off=192 * 256, resid=dA)        # d out5 += df0 @ Wn1[:,192:]
+        self._block_bwd(plan, P, "stage1.5", enc.stage1[5], dA, dB)
+        ops.gemm_nt([df0], wT[E + "neck1.weight"], dB, T1, 192, 256, resid=dB)                           # d out4 += df0 @ Wn1[:,:192]
+        cur, other = dB, dA
+        for i in reversed(range(5)):
+            self._block_bwd(plan, P, f"stage1.{i}", enc.stage1[i], cur, other)
+            cur, other = other, cur
+        # ---- patch_embed 1x1 + pos_embed
+        if plan.saved["use_pos"]:
+            ops.batch_sum(cur, g[E + "pos_embed"], B, t * t * 192)
+        ops.gemm_tn(cur, [SegSpec(b["x0"])], g[E + "patch_embed.proj.weight"], T1, 192, 192, dbias=g[E + "patch_embed.proj.bias"])
+        dx0 = plan.buf("g.dx0", (T1, 192))
+        ops.gemm_nt([SegSpec(cur)], wT[E + "patch_embed.proj.weight"], dx0, T1, 192, 192)

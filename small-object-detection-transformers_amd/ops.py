@@ -244,12 +244,21 @@ def prep_weights(table_dev, n, max_elems, dtype_code):
     _launch("sodt_prep_weights", _p(table_dev), n, max_elems, dtype_code)
 
 
-def transpose_f32(src, dst, rows, cols, accumulate=False):
-    _launch("sodt_transpose_f32", _p(src), _p(dst), rows, cols, 1 if accumulate else 0)
+def transpose_f32(src, dst, rows, cols, accumulate=0):
+    """accumulate: 0 store, 1 add, 2 add and clear src."""
+    _launch("sodt_transpose_f32", _p(src), _p(dst), rows, cols, int(accumulate))
+
+
+def zero_(t):
+    _launch("sodt_memset_zero", _p(t), t.numel() * t.element_size())
 
 
 def cast(src, dst, n):
     _launch("sodt_cast", _p(src), _p(dst), n, dt_code(src), dt_code(dst))
+
+
+def batch_sum(d, out, B, RC):
+    _launch("sodt_batch_sum", _p(d), _p(out), B, RC, dt_code(d))
 
 
 def version() -> str:
