@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the training step (forward + hand-written backward
++ SGD step, + RCCL gradient all-reduce when N > 1) of Model(SRyolo_MF.yaml) on synthetic
+1024x1024 RGB+IR batches, bf16 compute, batch 8 per GPU (BASELINE.json configs[1]/[2]).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - the dominant kernel (stage-1 fc1 GEMM of the MFMA GEMM family), timed live with
+                 HIP events on the launch stream inside the timed region
+  cpu_baseline - the CPU oracle (oracle/ref_torch.py, a port) timed on this host's cores on a
+                 bounded sample (1 image at 1024x1024, fwd+bwd), rank 0 at N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "small-object-detection-transformers_amd"
+
+FLOP_PER_IMG_1024 = 2101.55e9       # fwd+bwd, 2*MAC over linear/conv/attention matmuls
+PEAK_BF16 = 2500.0                  # TFLOP/s dense (MI355X_MICROARCH.md)
+PEAK_HBM = 8000.0                   # GB/s
+
+
+def build_model(S, dev, dtype):
+    import yaml
+    M = importlib.import_module(PKG + ".model")
+    cfg = yaml.safe_load(open(os.path.join(ROOT, PKG, "configs", "SRyolo_MF.yaml")))
+    cfg["backbone"][0][3][0] = S          # resolution parameter (the reference hard-codes 512)
+    torch.manual_seed(0)
+    model = M.Model(cfg, input_mode="RGB+IR", ch_steam=3, ch=128, nc=8).to(dev).train()
+    model.compute_dtype = dtype
+    return model
+
+
+def cpu_baseline(S=1024, iters=2):
+    """Oracle fwd+bwd on the host cores: 1 warm-up + `iters` timed images."""
+    from oracle import ref_torch as R
+    n = os.cpu_count() or 1
+    torch.set_num_threads(n)
+    sd = R.procedural_state_dict(S, 8)
+    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "anchor" not in k) for k, v in sd.items()}
+    x_rgb, x_ir = R.synthetic_inputs(1, S, seed=0)
+    ts = []
+    for i in range(iters + 1):
+        t0 = time.perf_counter()
+        pred, _ = R.model_forward(osd, x_rgb, x_ir, True, {})
+        pred[0].square().mean().backward()
+        ts.append(time.perf_counter() - t0)
+        for v in osd.values():
+            v.grad = None
+    best = min(ts[1:])
+    return {"value": round(1.0 / best, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/ref_torch.py fwd+bwd, {iters} x 1 image @ {S}x{S} f32 after 1 warm-up, best-of; "
+                      f"os.cpu_count()={n}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    B, S = a.batch, a.size
+    model = build_model(S, dev, dtype)
+    if world > 1:
+        ddp = importlib.import_module(PKG + ".ddp")
+        ddp.attach(model, average=True)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.937, nesterov=True)   # models/hyp.scratch.yaml
+    g = torch.Generator(device="cpu").manual_seed(2 + rank)                            # Train.py:72
+    x_rgb = torch.rand(B, 3, S, S, generator=g).to(dev)
+    x_ir = torch.rand(B, 3, S, S, generator=g).to(dev)
+
+    def step():
+        pred, _ = model(x_rgb, x_ir, "RGB+IR")
+        loss = pred[0].float().square().mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, 2)):        # >= 2: the first step records the launch plans
+        step()
+    # ---- live roofline probe: the stage-1 fc1 GEMM (M = B*t*t, N = 768, K = 192), forward
+    eng = model._get_engine()
+    plan = eng.plans[(B, S, dtype, True)]
+    idx = [i for i, c in enumerate(plan.fwd_main) if c[2] == "sodt_gemm_nt" and c[3] == "stage1.0"]
+    probe_i = idx[2]                         # qkv, proj, fc1, fc2 in issue order
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        eng.probes_fwd = {probe_i: evs[k]}
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.probes_fwd = None
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+
+    if rank == 0:
+        t = S // 4
+        Mrows = B * t * t
+        kern_ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
+        flops = 2.0 * Mrows * 768 * 192
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        img_s = world * B * a.steps / dt
+        out = {
+            "metric": "images/sec (1024x1024 RGB+IR) train fwd+bwd", "value": round(img_s, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"SRyolo_MF.yaml (model.yaml graph), batch {B}/GPU @ {S}x{S} RGB+IR, fwd + hand-written bwd "
+                                   f"+ SGD step, loss = mean(pred^2), random-init weights", "global_batch": world * B,
+                       "parallelism": f"dp{world}"},
+            "model_tflops": round(img_s * FLOP_PER_IMG_1024 * (S / 1024) ** 2 / 1e12, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16> stage1 fc1 (M=%d,N=768,K=192, bias+GELU dual store)" % Mrows,
+                         "achieved": round(achieved, 1), "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16, 4),
+                         "avg_launch_ms": round(kern_ms, 4), "traffic": None},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

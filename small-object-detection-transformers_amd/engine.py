@@ -82,6 +82,8 @@ class Engine:
         self.fused = not hasattr(model.detect[0], "bn")
         self._check_head()
         self.plans: Dict[Tuple, Plan] = {}
+        self.probes_fwd: Optional[dict] = None    # bench.py: {call index: (start event, end event)}
+        self.probes_bwd: Optional[dict] = None
         self.prep: Dict[torch.dtype, dict] = {}
         self._build_grad_buffer()
         # anchor that makes the autograd node require grad even if the caller froze everything else
@@ -267,7 +269,7 @@ class Engine:
                 self._forward_main(plan, P)
             plan.fwd_main = rec.calls
         else:
-            ops.replay(plan.fwd_main)
+            ops.replay(plan.fwd_main, probes=self.probes_fwd)
         # (4) Detect: live (fresh output tensor every call)
         T1 = B * t * t
         pred = torch.empty(B, self.na, t, t, self.no, device=self.dev, dtype=torch.float32)
@@ -330,6 +332,7 @@ class Engine:
         return ws, shift
 
     def _block_fwd(self, plan, P, tag, blk, x_in, B, H, W):
+        ops.set_tag(tag)
         p, w = self.params, P["w"]
         pre = E + tag + "."
         Cc = blk.dim
@@ -368,6 +371,7 @@ class Engine:
 
     def _block_bwd(self, plan, P, tag, blk, dY, dX):
         """dY: gradient wrt the block output; writes the gradient wrt the block input into dX."""
+        ops.set_tag(tag + ".bwd")
         p, wT, g, b = self.params, P["wT"], self.g, plan.bufs
         pre = E + tag + "."
         sv = plan.saved[tag]
@@ -415,6 +419,7 @@ class Engine:
 
     # ------------------------------------------------------------------ PatchMerging
     def _merge_fwd(self, plan, P, tag, x, B, H, W, Cc):
+        ops.set_tag(tag)
         p, w = self.params, P["w"]
         pre = E + tag + "."
         M2 = B * (H // 2) * (W // 2)
@@ -445,6 +450,7 @@ class Engine:
     # ------------------------------------------------------------------ head units
     def _conv_fwd(self, plan, P, tag, pname, segs, spatial, M, K, Cout, k):
         """Conv2d(bias=False)+BN+SiLU (common.py:38-50) as GEMM (+f64 column stats) -> finalize -> normalise+SiLU."""
+        ops.set_tag(tag)
         p, w, bufs = self.params, P["w"], self.buffers
         y = plan.buf(tag + ".y", (M, Cout))
         wname = pname + "conv.weight"
@@ -470,6 +476,7 @@ class Engine:
 
     def _conv_bwd(self, plan, tag, dy, lddy, dy_off):
         """BN+SiLU backward and the conv weight gradient; returns dz (gradient at the conv output)."""
+        ops.set_tag(tag + ".bwd")
         p, g, b = self.params, self.g, plan.bufs
         sv = plan.saved[tag]
         M, K, Cout, k, pname = sv["M"], sv["K"], sv["Cout"], sv["k"], sv["pname"]
@@ -537,7 +544,7 @@ class Engine:
                 self._backward_main(plan, P)
             plan.bwd_main = rec.calls
         else:
-            ops.replay(plan.bwd_main)
+            ops.replay(plan.bwd_main, probes=self.probes_bwd)
         # (3) front end: live
         fe = P["fe"]
         ops.frontend_bwd(x_rgb, x_ir, x_ir.shape[1] * S * S, fe["w"], fe["b"], fe["g"], fe["be"], plan.bufs["g.dx0"],

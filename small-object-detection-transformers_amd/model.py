@@ -387,6 +387,8 @@ class Model(nn.Module):
         if self._engine is None:
             from .engine import Engine          # imports the HIP library; raises if it is missing
             self._engine = Engine(self)
+            if getattr(self, "_pending_ddp", None) is not None:
+                self._engine.ddp = self._pending_ddp
         return self._engine
 
     def forward(self, x, ir=None, input_mode="RGB+IR", augment=False, profile=False):

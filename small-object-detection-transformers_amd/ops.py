@@ -39,12 +39,33 @@ class Recorder:
         return False
 
 
-def replay(calls: Sequence[Tuple], stream: Optional[int] = None) -> None:
+_tag: str = ""          # label attached to recorded launches (set by the engine, read by bench probes)
+
+
+def set_tag(tag: str) -> None:
+    global _tag
+    _tag = tag
+
+
+def replay(calls: Sequence[Tuple], stream: Optional[int] = None, probes: Optional[dict] = None) -> None:
+    """Re-issue recorded launches.  probes: {call index: (start_event, end_event)} -> the events are
+    recorded on the launch stream around that one kernel (bench.py's live roofline measurement)."""
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
-    for fn, args, name in calls:
+    if probes:
+        for i, (fn, args, name, tag) in enumerate(calls):
+            pr = probes.get(i)
+            if pr is not None:
+                pr[0].record()
+            rc = fn(*args, st)
+            if pr is not None:
+                pr[1].record()
+            if rc != 0:
+                raise RuntimeError(f"{name} failed with status {rc}")
+        return
+    for fn, args, name, tag in calls:
         rc = fn(*args, st)
         if rc != 0:
-            raise RuntimeError(f"{name} failed with status {rc}")
+            raise RuntimeError(f"{name} [{tag}] failed with status {rc}")
 
 
 def _launch(name: str, *args) -> None:
@@ -54,7 +75,7 @@ def _launch(name: str, *args) -> None:
     if rc != 0:
         raise RuntimeError(f"{name} failed with status {rc} (unsupported shape/alignment, see include/sodt_hip.h)")
     if _active_recorder is not None:
-        _active_recorder.append((fn, args, name))
+        _active_recorder.append((fn, args, name, _tag))
 
 
 def dt_code(t: torch.Tensor) -> int:
