@@ -69,6 +69,29 @@ __device__ __forceinline__ uint4 frag(const unsigned char* tile, int rowbytes, i
   return *(const uint4*)(tile + (row0 + (lane & 15)) * rowbytes + k * TT<T>::SZ);
 }
 
+// MFMA operand fragment whose contraction index runs along the LDS ROWS of a [K rows][cols] tile
+// (lane reads column col0 + (l&15), rows k0 + KPL*(l>>4) .. +KPL-1): bf16 through the transposing
+// ds_read_b64_tr_b16 (two reads of 4 rows), f32 through four strided ds_read_b32.  EXEC must be full.
+template <typename T> __device__ __forceinline__ uint4 fragT(const unsigned char* tile, int rowbytes, int k0, int col0, int lane);
+template <> __device__ __forceinline__ uint4 fragT<bf16>(const unsigned char* tile, int rowbytes, int k0, int col0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned char* a = tile + (k0 + 8 * g + q) * rowbytes + (col0 + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  union { s16x4 v; uint2 u; } lo, hi;
+  lo.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  hi.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * rowbytes));
+  return make_uint4(lo.u.x, lo.u.y, hi.u.x, hi.u.y);
+}
+template <> __device__ __forceinline__ uint4 fragT<float>(const unsigned char* tile, int rowbytes, int k0, int col0, int lane) {
+  const unsigned char* a = tile + (k0 + 4 * (lane >> 4)) * rowbytes + (col0 + (lane & 15)) * 4;
+  uint4 r;
+  r.x = *(const uint32_t*)(a);
+  r.y = *(const uint32_t*)(a + rowbytes);
+  r.z = *(const uint32_t*)(a + 2 * rowbytes);
+  r.w = *(const uint32_t*)(a + 3 * rowbytes);
+  return r;
+}
+
 template <typename T> __device__ __forceinline__ void st_elem(unsigned char* p, float v) { *(T*)p = from_f<T>(v); }
 
 // store 4 consecutive elements (accumulator rows 4g..4g+3 of one column) into a transposed tile
@@ -91,10 +114,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
   constexpr int NT = NW * 64;
   __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE];
   __shared__ __attribute__((aligned(16))) unsigned char sK[NW * L::QTILE];
-  __shared__ __attribute__((aligned(16))) unsigned char sVT[NW * L::TTILE];
+  __shared__ __attribute__((aligned(16))) unsigned char sV[NW * L::QTILE];
   __shared__ __attribute__((aligned(16))) unsigned char sP[NW * L::STILE];
   __shared__ int sTokQ[64], sTokK[64];
   __shared__ short sGeoQ[64][4], sGeoK[64][4];   // iy, ix, rid, -
+  __shared__ float sBias[NW][228];               // bias rows reachable from this (q tile, kv tile) pair
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int HG = g.heads / NW;
@@ -135,15 +159,23 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
   }
   const unsigned char* myQ = sQ + w * L::QTILE;
   const unsigned char* myK = sK + w * L::QTILE;
-  const unsigned char* myVT = sVT + w * L::TTILE;
+  const unsigned char* myV = sV + w * L::QTILE;
   unsigned char* myP = sP + w * L::STILE;
   const float* bt = bias_t + (long)head * L2 * L2;
+  const int R = g.ws >= 64 ? 1 : 64 / g.ws;     // window rows per 64-token tile
+  const int LT = (2 * R - 1) * L2;
 
   for (int kt = 0; kt < g.nqt; ++kt) {
     if (tid < 64) {
       int row, rid, iy, ix;
       win_token(g, b, wy, wx, kt * 64 + tid, row, rid, iy, ix);
       sTokK[tid] = row; sGeoK[tid][0] = (short)iy; sGeoK[tid][1] = (short)ix; sGeoK[tid][2] = (short)rid;
+    }
+    const int dyoff = (qt - kt) * R;
+    for (int i = lane; i < LT; i += 64) {
+      const int a = i / L2, c = i - a * L2;
+      const int gy = a - (R - 1) + dyoff + g.ws - 1;
+      sBias[w][i] = (gy >= 0 && gy < L2) ? bt[gy * L2 + c] : 0.f;
     }
     __syncthreads();
     for (int idx = tid; idx < 64 * CPR; idx += NT) {
@@ -153,10 +185,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
       const uint4 kv = *(const uint4*)(src + g.C);
       const uint4 vv = *(const uint4*)(src + 2 * g.C);
       *(uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16) = kv;
-      union { uint4 u; T e[KPL]; } tmp;
-      tmp.u = vv;
-#pragma unroll
-      for (int j = 0; j < KPL; ++j) *(T*)(sVT + h * L::TTILE + (dc * KPL + j) * L::TROW + r * E) = tmp.e[j];
+      *(uint4*)(sV + (h * 64 + r) * L::QROW + dc * 16) = vv;
     }
     __syncthreads();
 
@@ -187,7 +216,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
         float mx = -1e30f;
 #pragma unroll
         for (int ns = 0; ns < 4; ++ns) {
-          float v = s[ns][r] * scale + bt[(qiy - kiy[ns] + g.ws - 1) * L2 + (qix - kix[ns] + g.ws - 1)];
+          float v = s[ns][r] * scale + sBias[w][(qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1)];
           if (qrid != krid[ns]) v += -100.0f;
           s[ns][r] = v;
           mx = fmaxf(mx, v);
@@ -213,7 +242,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
     for (int kb = 0; kb < L::KBT; ++kb) {
       uint4 fb[HD / 16];
 #pragma unroll
-      for (int d = 0; d < HD / 16; ++d) fb[d] = frag<T>(myVT, L::TROW, d * 16, kb, 64, lane);
+      for (int d = 0; d < HD / 16; ++d) fb[d] = fragT<T>(myV, L::QROW, kb * TT<T>::MMA_K, d * 16, lane);
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms) {
         const uint4 fa = frag<T>(myP, L::TROW, ms * 16, kb, 64, lane);
@@ -283,38 +312,44 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
   constexpr int E = L::E, KPL = L::KPL;
   constexpr int NT = NW * 64;
   constexpr int LTMAX = 225;
+  constexpr int MK = TT<T>::MMA_K;
+  // only row-major [token][d] tiles are staged; every "transposed" MFMA operand is read with fragT
   __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE], sK[NW * L::QTILE], sV[NW * L::QTILE],
       sDO[NW * L::QTILE];
-  __shared__ __attribute__((aligned(16))) unsigned char sQT[NW * L::TTILE], sKT[NW * L::TTILE], sDOT[NW * L::TTILE];
-  __shared__ __attribute__((aligned(16))) unsigned char sPT[NW * L::STILE], sDS[NW * L::STILE];
+  __shared__ __attribute__((aligned(16))) unsigned char sPT[NW * L::STILE], sDST[NW * L::STILE];   // [key][q]
   __shared__ float sDB[NW][LTMAX + 3];
+  __shared__ float sBias[NW][LTMAX + 3];
+  __shared__ float sLse[NW][64], sDelta[NW][64];
   __shared__ int sTokQ[64], sTokK[64];
   __shared__ short sGeoQ[64][4], sGeoK[64][4];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int HG = g.heads / NW;
   const int hg = blockIdx.y;
   const int head = hg * NW + w;
   const int C3 = 3 * g.C;
   const int L2 = 2 * g.ws - 1;
-  const int R = 64 / g.ws > 0 ? (g.ws >= 64 ? 1 : 64 / g.ws) : 1;   // window rows per 64-token tile
+  const int R = g.ws >= 64 ? 1 : 64 / g.ws;      // window rows per 64-token tile
   const int LT = (2 * R - 1) * L2;
   const bool single = g.nqt == 1;
   const float scale = rsqrtf((float)HD);
   const float* bt = bias_t + (long)head * L2 * L2;
   constexpr int CPR = NW * L::DCH;
-  (void)HG;
 
   for (int i = tid; i < NW * (LTMAX + 3); i += NT) (&sDB[0][0])[i] = 0.f;
 
   unsigned char* myQ = sQ + w * L::QTILE; unsigned char* myK = sK + w * L::QTILE;
   unsigned char* myV = sV + w * L::QTILE; unsigned char* myDO = sDO + w * L::QTILE;
-  unsigned char* myQT = sQT + w * L::TTILE; unsigned char* myKT = sKT + w * L::TTILE;
-  unsigned char* myDOT = sDOT + w * L::TTILE;
-  unsigned char* myPT = sPT + w * L::STILE; unsigned char* myDS = sDS + w * L::STILE;
+  unsigned char* myPT = sPT + w * L::STILE; unsigned char* myDST = sDST + w * L::STILE;
 
-  // work items: (window, kv tile); grid-stride so that the LDS bias-gradient table is flushed rarely
+  // relative-position-bias gradient: dS summed in registers over every window this wave visits (the
+  // (q, key) -> table-entry map is the same for all of them), reduced through LDS only when it changes
+  f32x4 dbacc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbacc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   const int nitems = nwin_total * g.nqt;
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     int t = item;
@@ -329,19 +364,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
       sTokK[tid] = row; sGeoK[tid][0] = (short)iy; sGeoK[tid][1] = (short)ix; sGeoK[tid][2] = (short)rid;
     }
     __syncthreads();
-    // K (+K^T) and V tiles of this kv tile
     for (int idx = tid; idx < 64 * CPR; idx += NT) {
       const int r = idx / CPR, cc = idx - r * CPR;
       const int h = cc / L::DCH, dc = cc - h * L::DCH;
       const T* src = qkv + (long)sTokK[r] * C3 + (hg * NW) * HD + cc * KPL;
-      const uint4 kv = *(const uint4*)(src + g.C);
-      const uint4 vv = *(const uint4*)(src + 2 * g.C);
-      *(uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16) = kv;
-      *(uint4*)(sV + (h * 64 + r) * L::QROW + dc * 16) = vv;
-      union { uint4 u; T e[KPL]; } tmp;
-      tmp.u = kv;
-#pragma unroll
-      for (int j = 0; j < KPL; ++j) *(T*)(sKT + h * L::TTILE + (dc * KPL + j) * L::TROW + r * E) = tmp.e[j];
+      *(uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(src + g.C);
+      *(uint4*)(sV + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(src + 2 * g.C);
     }
     f32x4 dk[4][HD / 16], dv[4][HD / 16];
 #pragma unroll
@@ -357,31 +385,31 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
         sTokQ[tid] = row; sGeoQ[tid][0] = (short)iy; sGeoQ[tid][1] = (short)ix; sGeoQ[tid][2] = (short)rid;
       }
       __syncthreads();
+      const int dyoff = (qt - kt) * R;
+      {
+        for (int i = lane; i < LT; i += 64) {
+          const int a = i / L2, c = i - a * L2;
+          const int gy = a - (R - 1) + dyoff + g.ws - 1;
+          sBias[w][i] = (gy >= 0 && gy < L2) ? bt[gy * L2 + c] : 0.f;
+        }
+        const long tq = sTokQ[lane];
+        sLse[w][lane] = lse[tq * g.heads + head];
+        sDelta[w][lane] = single ? 0.f : delta[tq * g.heads + head];
+      }
       for (int idx = tid; idx < 64 * CPR; idx += NT) {
         const int r = idx / CPR, cc = idx - r * CPR;
         const int h = cc / L::DCH, dc = cc - h * L::DCH;
-        const uint4 qv = *(const uint4*)(qkv + (long)sTokQ[r] * C3 + (hg * NW) * HD + cc * KPL);
-        const uint4 dv_ = *(const uint4*)(d_out + (long)sTokQ[r] * g.C + (hg * NW) * HD + cc * KPL);
-        *(uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16) = qv;
-        *(uint4*)(sDO + (h * 64 + r) * L::QROW + dc * 16) = dv_;
-        union { uint4 u; T e[KPL]; } t1, t2;
-        t1.u = qv; t2.u = dv_;
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-          *(T*)(sQT + h * L::TTILE + (dc * KPL + j) * L::TROW + r * E) = t1.e[j];
-          *(T*)(sDOT + h * L::TTILE + (dc * KPL + j) * L::TROW + r * E) = t2.e[j];
-        }
+        *(uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(qkv + (long)sTokQ[r] * C3 + (hg * NW) * HD + cc * KPL);
+        *(uint4*)(sDO + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(d_out + (long)sTokQ[r] * g.C + (hg * NW) * HD + cc * KPL);
       }
       __syncthreads();
 
-      // ---- phase A: per 16-query strip  S, dP -> P, dS ; P^T and dS to LDS ; bias grad to the LDS table
-      f32x4 dsr[4][4];
+      // ---- phase A: per 16-query strip  S, dP -> P, dS ; P^T and dS^T to LDS (packed 4-q stores)
       int kiy[4], kix[4], krid[4];
 #pragma unroll
       for (int ns = 0; ns < 4; ++ns) {
         kiy[ns] = sGeoK[ns * 16 + fr][0]; kix[ns] = sGeoK[ns * 16 + fr][1]; krid[ns] = sGeoK[ns * 16 + fr][2];
       }
-      const int dyoff = (qt - kt) * R;
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms) {
         f32x4 s[4], dp[4];
@@ -403,112 +431,99 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
         for (int r = 0; r < 4; ++r) {
           const int qn = ms * 16 + fg * 4 + r;
           const int qiy = sGeoQ[qn][0], qix = sGeoQ[qn][1], qrid = sGeoQ[qn][2];
-          const long tq = sTokQ[qn];
-          const float lq = lse[tq * g.heads + head];
+          const float lq = sLse[w][qn];
           float dl = 0.f;
 #pragma unroll
           for (int ns = 0; ns < 4; ++ns) {
-            float v = s[ns][r] * scale + bt[(qiy - kiy[ns] + g.ws - 1) * L2 + (qix - kix[ns] + g.ws - 1)];
+            float v = s[ns][r] * scale + sBias[w][(qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1)];
             if (qrid != krid[ns]) v += -100.0f;
             const float p = fast_exp(v - lq);
             s[ns][r] = p;
             dl += p * dp[ns][r];
           }
           if (single) dl = group16_sum(dl);
-          else dl = delta[tq * g.heads + head];
+          else dl = sDelta[w][qn];
 #pragma unroll
           for (int ns = 0; ns < 4; ++ns) {
             const float ds = s[ns][r] * (dp[ns][r] - dl);
-            dsr[ms][ns][r] = ds;
-            const int li = (qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1);
-            atomicAdd(&sDB[w][li], ds);
-            st_elem<T>(myDS + qn * L::TROW + (ns * 16 + fr) * E, ds);
+            dp[ns][r] = ds;
+            dbacc[ms][ns][r] += ds;
           }
         }
 #pragma unroll
-        for (int ns = 0; ns < 4; ++ns) st4<T>(myPT + (ns * 16 + fr) * L::TROW + (ms * 16 + fg * 4) * E, s[ns]);
+        for (int ns = 0; ns < 4; ++ns) {
+          st4<T>(myPT + (ns * 16 + fr) * L::TROW + (ms * 16 + fg * 4) * E, s[ns]);
+          st4<T>(myDST + (ns * 16 + fr) * L::TROW + (ms * 16 + fg * 4) * E, dp[ns]);
+        }
       }
       __syncthreads();
 
-      // ---- phase B1: dV += P^T dO ;  dQ = scale * dS K
+      // ---- phase B: dV += P^T dO ; dK += dS^T Q ; dQ = dS K   (contraction over LDS rows -> fragT)
+      f32x4 dq[4][HD / 16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) dq[i][d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < L::KBT; ++kb) {
-        uint4 fb[HD / 16];
+        uint4 fdo[HD / 16], fqq[HD / 16], fkk[HD / 16];
 #pragma unroll
-        for (int d = 0; d < HD / 16; ++d) fb[d] = frag<T>(myDOT, L::TROW, d * 16, kb, 64, lane);
+        for (int d = 0; d < HD / 16; ++d) {
+          fdo[d] = fragT<T>(myDO, L::QROW, kb * MK, d * 16, lane);
+          fqq[d] = fragT<T>(myQ, L::QROW, kb * MK, d * 16, lane);
+          fkk[d] = fragT<T>(myK, L::QROW, kb * MK, d * 16, lane);
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const uint4 fa = frag<T>(myPT, L::TROW, ks * 16, kb, 64, lane);
+          const uint4 fp = frag<T>(myPT, L::TROW, ks * 16, kb, 64, lane);
+          const uint4 fs = frag<T>(myDST, L::TROW, ks * 16, kb, 64, lane);
+          const uint4 fst = fragT<T>(myDST, L::TROW, kb * MK, ks * 16, lane);    // dS[q = ks strip][key block kb]
 #pragma unroll
-          for (int d = 0; d < HD / 16; ++d) mma16<T>(dv[ks][d], fa, fb[d]);
-        }
-      }
-      {
-        f32x4 dq[4][HD / 16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int d = 0; d < HD / 16; ++d) dq[i][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < L::KBT; ++kb) {
-          uint4 fb[HD / 16];
-#pragma unroll
-          for (int d = 0; d < HD / 16; ++d) fb[d] = frag<T>(myKT, L::TROW, d * 16, kb, 64, lane);
-#pragma unroll
-          for (int ms = 0; ms < 4; ++ms) {
-            const uint4 fa = frag<T>(myDS, L::TROW, ms * 16, kb, 64, lane);
-#pragma unroll
-            for (int d = 0; d < HD / 16; ++d) mma16<T>(dq[ms][d], fa, fb[d]);
+          for (int d = 0; d < HD / 16; ++d) {
+            mma16<T>(dv[ks][d], fp, fdo[d]);
+            mma16<T>(dk[ks][d], fs, fqq[d]);
+            mma16<T>(dq[ks][d], fst, fkk[d]);
           }
         }
-        __syncthreads();   // every wave is done reading sQ / sDO / sPT of this pair
-        if (single) {
-#pragma unroll
-          for (int ms = 0; ms < 4; ++ms)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int d = 0; d < HD / 16; ++d)
-                st_elem<T>(myQ + (ms * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dq[ms][d][r] * scale);
-        } else {
-#pragma unroll
-          for (int ms = 0; ms < 4; ++ms)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const long tq = sTokQ[ms * 16 + fg * 4 + r];
-#pragma unroll
-              for (int d = 0; d < HD / 16; ++d)
-                atomicAdd(dq_acc + tq * g.C + head * HD + d * 16 + fr, dq[ms][d][r] * scale);
-            }
-        }
       }
-      // ---- phase B2: dS^T (from registers) into the P^T tile, then dK += dS^T Q
+      __syncthreads();   // every wave is done reading sQ / sDO / sPT / sDST of this pair
+      if (single) {
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms)
+        for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
-        for (int ns = 0; ns < 4; ++ns) st4<T>(myPT + (ns * 16 + fr) * L::TROW + (ms * 16 + fg * 4) * E, dsr[ms][ns]);
-      __syncthreads();
-      if (single) {   // dQ tile (staged in sQ) -> dqkv[:, 0:C]
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d)
+              st_elem<T>(myQ + (ms * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dq[ms][d][r] * scale);
+        __syncthreads();
         for (int idx = tid; idx < 64 * CPR; idx += NT) {
           const int r = idx / CPR, cc = idx - r * CPR;
           const int h = cc / L::DCH, dc = cc - h * L::DCH;
           *(uint4*)(dqkv + (long)sTokQ[r] * C3 + (hg * NW) * HD + cc * KPL) = *(const uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16);
         }
-      }
+      } else {
 #pragma unroll
-      for (int kb = 0; kb < L::KBT; ++kb) {
-        uint4 fb[HD / 16];
+        for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
-        for (int d = 0; d < HD / 16; ++d) fb[d] = frag<T>(myQT, L::TROW, d * 16, kb, 64, lane);
+          for (int r = 0; r < 4; ++r) {
+            const long tq = sTokQ[ms * 16 + fg * 4 + r];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const uint4 fa = frag<T>(myPT, L::TROW, ks * 16, kb, 64, lane);
+            for (int d = 0; d < HD / 16; ++d)
+              atomicAdd(dq_acc + tq * g.C + head * HD + d * 16 + fr, dq[ms][d][r] * scale);
+          }
+        // the (q tile, kv tile) offset changes with every pair: reduce the register sums into the LDS table now
 #pragma unroll
-          for (int d = 0; d < HD / 16; ++d) mma16<T>(dk[ks][d], fa, fb[d]);
-        }
-      }
-      // ---- flush the bias-gradient table when the (q tile, kv tile) offset changes
-      if (!single) {
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qn = ms * 16 + fg * 4 + r;
+            const int qiy = sGeoQ[qn][0], qix = sGeoQ[qn][1];
+#pragma unroll
+            for (int ns = 0; ns < 4; ++ns) {
+              atomicAdd(&sDB[w][(qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1)], dbacc[ms][ns][r]);
+              dbacc[ms][ns][r] = 0.f;
+            }
+          }
         __syncthreads();
         for (int i = lane; i < LT; i += 64) {
           const int a = i / L2, c = i - a * L2;
@@ -540,6 +555,24 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
     }
   }
   if (single) {
+    // one reduction for all the windows this wave handled: registers -> LDS table -> global atomics
+    // (window-local geometry is identical for every window, so the last sGeoQ / sGeoK are valid)
+    __syncthreads();
+    if (nitems > (int)blockIdx.x) {
+      int kiy[4], kix[4];
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) { kiy[ns] = sGeoK[ns * 16 + fr][0]; kix[ns] = sGeoK[ns * 16 + fr][1]; }
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qn = ms * 16 + fg * 4 + r;
+          const int qiy = sGeoQ[qn][0], qix = sGeoQ[qn][1];
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns)
+            atomicAdd(&sDB[w][(qiy - kiy[ns] + R - 1) * L2 + (qix - kix[ns] + g.ws - 1)], dbacc[ms][ns][r]);
+        }
+    }
     __syncthreads();
     for (int i = lane; i < LT; i += 64) {
       const float v = sDB[w][i];
@@ -621,10 +654,10 @@ extern "C" int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const 
   if (dtype == SODT_BF16) {
     if (hd == 16) return launch_bwd<bf16, 16, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
     if (hd == 32) return launch_bwd<bf16, 32, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
-    if (hd == 64) return launch_bwd<bf16, 64, 1>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
+    if (hd == 64) return launch_bwd<bf16, 64, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
   } else if (dtype == SODT_F32) {
     if (hd == 16) return launch_bwd<float, 16, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
-    if (hd == 32) return launch_bwd<float, 32, 1>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
+    if (hd == 32) return launch_bwd<float, 32, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
     if (hd == 64) return launch_bwd<float, 64, 1>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
   }
   return SODT_EINVAL;

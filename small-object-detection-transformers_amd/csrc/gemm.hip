@@ -212,13 +212,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
     }
     const bool full = (n + KPL <= g.N);
     if (flags & SODT_EPI_BIAS) {
+      if (full) {
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) if (full || n + j < g.N) v[j] += g.bias[n + j];
+        for (int j = 0; j < KPL; j += 4) {
+          const float4 bb = *(const float4*)(g.bias + n + j);
+          v[j] += bb.x; v[j + 1] += bb.y; v[j + 2] += bb.z; v[j + 3] += bb.w;
+        }
+      } else {
+        for (int j = 0; j < KPL; ++j) if (n + j < g.N) v[j] += g.bias[n + j];
+      }
     }
     if (flags & SODT_EPI_AFFINE_SILU) {
+      float sc[KPL], sh[KPL];
+      if (full) {
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) if (full || n + j < g.N) {
-        const float a = v[j] * g.scale[n + j] + g.shift[n + j];
+        for (int j = 0; j < KPL; j += 4) {
+          const float4 a4 = *(const float4*)(g.scale + n + j);
+          const float4 b4 = *(const float4*)(g.shift + n + j);
+          sc[j] = a4.x; sc[j + 1] = a4.y; sc[j + 2] = a4.z; sc[j + 3] = a4.w;
+          sh[j] = b4.x; sh[j + 1] = b4.y; sh[j + 2] = b4.z; sh[j + 3] = b4.w;
+        }
+      } else {
+        for (int j = 0; j < KPL; ++j) { sc[j] = (n + j < g.N) ? g.scale[n + j] : 0.f; sh[j] = (n + j < g.N) ? g.shift[n + j] : 0.f; }
+      }
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) {
+        const float a = v[j] * sc[j] + sh[j];
         v[j] = a * sigmoid_f(a);
       }
     }
@@ -457,12 +476,12 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
     const int okpl = (g->flags & SODT_EPI_OUT_F32) ? 1 : kpl;
     if ((g->ldc % okpl) || (((uintptr_t)g->C) & 15)) return SODT_EINVAL;
   } else if (g->det_na * g->det_no != g->N || g->det_hw <= 0) return SODT_EINVAL;
-  if ((g->flags & SODT_EPI_BIAS) && !g->bias) return SODT_EINVAL;
+  if ((g->flags & SODT_EPI_BIAS) && (!g->bias || (((uintptr_t)g->bias) & 15))) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_RESID) && (!g->R || (g->ldr % kpl))) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_DGELU) && (!g->aux || (g->ldaux % kpl))) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_GELU_DUAL) && (!g->C2 || (g->ldc2 % kpl))) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_STATS) && !g->stats) return SODT_EINVAL;
-  if ((g->flags & SODT_EPI_AFFINE_SILU) && (!g->scale || !g->shift)) return SODT_EINVAL;
+  if ((g->flags & SODT_EPI_AFFINE_SILU) && (!g->scale || !g->shift || ((((uintptr_t)g->scale) | ((uintptr_t)g->shift)) & 15))) return SODT_EINVAL;
   if (g->oscatter && !g->a.spatial) return SODT_EINVAL;
   const long tiles = ((long)(g->M + BM - 1) / BM) * ((g->N + BN - 1) / BN);
   if (tiles > 0x7fffffffL) return SODT_EINVAL;
