@@ -81,6 +81,8 @@ typedef struct {
  * input-gradient GEMM of the path (backbone_vit.py:968,990,886-904,857,213,268-270;
  * common.py:43,49; model.py:53). */
 int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st);
+/* test hook: 1 forces the K-loop tile kernel even where the A-stationary kernel applies, 0 = automatic */
+int sodt_gemm_set_variant(int force_tiled);
 
 typedef struct {
   const void* dY; int ldy;      /* [M][N] run dtype; ldy >= N rounded up to 16 bytes (pad columns must be zero) */

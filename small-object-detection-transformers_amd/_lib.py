@@ -83,6 +83,7 @@ SIGNATURES = {
     "sodt_cast": [_P, _P, _L, _I, _I, _P],
     "sodt_batch_sum": [_P, _P, _I, _L, _I, _P],
     "sodt_memset_zero": [_P, _L, _P],
+    "sodt_gemm_set_variant": [_I],
 }
 
 _lib = None

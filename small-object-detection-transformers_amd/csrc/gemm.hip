@@ -44,6 +44,84 @@ __device__ __forceinline__ sodt_seg pick_seg(const sodt_aspec& a, int i) {
   return s;
 }
 
+// fused epilogue of one 16-byte output chunk: v[KPL] = accumulators of row m, columns n .. n+KPL-1
+template <typename T>
+__device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int flags, const long m, const int n,
+                                          float (&v)[TT<T>::KPL], const int hw) {
+  constexpr int KPL = TT<T>::KPL;
+  const bool out32 = (flags & SODT_EPI_OUT_F32) != 0;
+  const bool full = (n + KPL <= g.N);
+  if (flags & SODT_EPI_BIAS) {
+    if (full) {
+#pragma unroll
+      for (int j = 0; j < KPL; j += 4) {
+        const float4 bb = *(const float4*)(g.bias + n + j);
+        v[j] += bb.x; v[j + 1] += bb.y; v[j + 2] += bb.z; v[j + 3] += bb.w;
+      }
+    } else {
+      for (int j = 0; j < KPL; ++j) if (n + j < g.N) v[j] += g.bias[n + j];
+    }
+  }
+  if (flags & SODT_EPI_AFFINE_SILU) {
+    float sc[KPL], sh[KPL];
+    if (full) {
+#pragma unroll
+      for (int j = 0; j < KPL; j += 4) {
+        const float4 a4 = *(const float4*)(g.scale + n + j);
+        const float4 b4 = *(const float4*)(g.shift + n + j);
+        sc[j] = a4.x; sc[j + 1] = a4.y; sc[j + 2] = a4.z; sc[j + 3] = a4.w;
+        sh[j] = b4.x; sh[j + 1] = b4.y; sh[j + 2] = b4.z; sh[j + 3] = b4.w;
+      }
+    } else {
+      for (int j = 0; j < KPL; ++j) { sc[j] = (n + j < g.N) ? g.scale[n + j] : 0.f; sh[j] = (n + j < g.N) ? g.shift[n + j] : 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const float a = v[j] * sc[j] + sh[j];
+      v[j] = a * sigmoid_f(a);
+    }
+  }
+  if (flags & SODT_EPI_DGELU) {
+    float x[KPL];
+    const T* ap = (const T*)g.aux + m * g.ldaux + n;
+    if (full) { unpack<T>(*(const uint4*)ap, x); }
+    else { for (int j = 0; j < KPL; ++j) x[j] = (n + j < g.N) ? to_f(ap[j]) : 0.f; }
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) v[j] *= dgelu_f(x[j]);
+  }
+  if (flags & SODT_EPI_RESID) {
+    const long rr = g.rmod > 0 ? (m % g.rmod) : m;
+    float x[KPL];
+    const T* rp = (const T*)g.R + rr * g.ldr + n;
+    if (full) { unpack<T>(*(const uint4*)rp, x); }
+    else { for (int j = 0; j < KPL; ++j) x[j] = (n + j < g.N) ? to_f(rp[j]) : 0.f; }
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) v[j] += x[j];
+  }
+  long orow = m;
+  if (g.oscatter) {
+    const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+    const int y = rem / g.a.Wo, x = rem - y * g.a.Wo;
+    orow = ((long)b * g.OH + y * g.omul + g.ody) * g.OW + x * g.omul + g.odx;
+  }
+  if (out32) {
+    float* cp = (float*)g.C + orow * g.ldc + n;
+    for (int j = 0; j < KPL; ++j) if (full || n + j < g.N) cp[j] = v[j];
+  } else {
+    T* cp = (T*)g.C + orow * g.ldc + n;
+    if (full) *(uint4*)cp = pack<T>(v);
+    else for (int j = 0; j < KPL; ++j) if (n + j < g.N) cp[j] = from_f<T>(v[j]);
+    if (flags & SODT_EPI_GELU_DUAL) {
+      float a[KPL];
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) a[j] = gelu_f(v[j]);
+      T* c2 = (T*)g.C2 + orow * g.ldc2 + n;
+      if (full) *(uint4*)c2 = pack<T>(a);
+      else for (int j = 0; j < KPL; ++j) if (n + j < g.N) c2[j] = from_f<T>(a[j]);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g) {
   constexpr int KPL = TT<T>::KPL;
@@ -52,8 +130,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
   __shared__ __attribute__((aligned(16))) unsigned char smem[NT_LDS];
   unsigned char* sA = smem;                   // [2][STAGE_BYTES]
   unsigned char* sB = smem + 2 * STAGE_BYTES; // [2][STAGE_BYTES]
+  __shared__ sodt_seg sSeg[SODT_MAX_SEG];     // segment table (dynamic indexing of kernel arguments would go to scratch)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) {
+#pragma unroll
+    for (int j = 0; j < SODT_MAX_SEG; ++j) sSeg[j] = g.a.s[j];
+  }
+  __syncthreads();
   const int wr = wid >> 1, wc = wid & 1;
   const int ntn = (g.N + BN - 1) / BN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -89,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
       a_off -= seg.klen;
       ++a_seg;
       if (a_seg < g.a.nseg) {
-        seg = pick_seg(g.a, a_seg);
+        seg = sSeg[a_seg];
 #pragma unroll
         for (int i = 0; i < 4; ++i) srow[i] = seg_src_row(seg, geo[i], g.a.spatial, m0 + lrow + 32 * i);
       }
@@ -198,7 +282,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
     return;
   }
 
-  const bool out32 = (flags & SODT_EPI_OUT_F32) != 0;
   constexpr int CPR = BN / KPL;   // chunks per row
   for (int idx = tid; idx < BM * CPR; idx += 256) {
     const int r = idx / CPR, c = (idx - r * CPR) * KPL;
@@ -210,77 +293,375 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
       const float4 t = *(const float4*)(sC + r * EPI_LD + c + j);
       v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
     }
-    const bool full = (n + KPL <= g.N);
-    if (flags & SODT_EPI_BIAS) {
-      if (full) {
+    epi_chunk<T>(g, flags, m, n, v, hw);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// A-stationary variant for short contractions (K * sizeof(T) <= 768 bytes: every C = 192 GEMM of
+// stage 1, C = 384 in bf16, the head's 1x1 convs).  One workgroup keeps its 64 rows of A -- the whole
+// K extent -- in LDS and walks ALL column tiles of the output: A is read from HBM exactly once, the
+// small weight matrix streams from L2 with a register-staged prefetch of the next tile under the
+// MFMAs and the epilogue of the current one, and the workgroup lives long enough to keep stores and
+// loads in flight back to back.  These GEMMs are HBM-bound (AI = N*K/(N+K) < 200 flop/B), so the
+// target is the output-store rate, not the MFMA rate.
+// ---------------------------------------------------------------------------------
+constexpr int AS_BM = 64;
+
+template <typename T, int BN_>
+__global__ __launch_bounds__(256, 2) void gemm_as_kernel(const sodt_gemm_args g) {
+  constexpr int KPL = TT<T>::KPL;
+  constexpr int MK = TT<T>::MMA_K;
+  constexpr int NSUB = BN_ / 32;               // 16-col subtiles per wave (2 waves across N)
+  constexpr int ELD = BN_ + 4;                 // padded f32 row of the staged accumulator tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  const int KB = g.K * (int)sizeof(T);         // bytes per row, multiple of 128
+  const int CPRK = KB >> 4;                    // 16-byte chunks per row
+  unsigned char* sA = dsm;                     // [64][KB]   swizzled
+  unsigned char* sW = dsm + AS_BM * KB;        // [BN][KB]   swizzled; aliased by the f32 staging tile
+  float* sC = (float*)sW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const long m0 = (long)blockIdx.x * AS_BM;
+  const int hw = g.a.Ho * g.a.Wo;
+  const int flags = g.flags;
+
+  // ---- A tile: every 16-byte chunk finds its K-segment and (spatially mapped) source row
+  for (int id = tid; id < AS_BM * CPRK; id += 256) {
+    const int r = id / CPRK, c = id - r * CPRK;
+    const long m = m0 + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m < g.M) {
+      int kcol = c * KPL, si = 0;
+      sodt_seg sg = g.a.s[0];
 #pragma unroll
-        for (int j = 0; j < KPL; j += 4) {
-          const float4 bb = *(const float4*)(g.bias + n + j);
-          v[j] += bb.x; v[j + 1] += bb.y; v[j + 2] += bb.z; v[j + 3] += bb.w;
+      for (int j = 1; j < SODT_MAX_SEG; ++j) {
+        if (j < g.a.nseg && si == j - 1 && kcol >= sg.klen) { kcol -= sg.klen; si = j; sg = g.a.s[j]; }
+      }
+      RowGeo geo; geo.ok = true; geo.b = 0; geo.y = 0; geo.x = 0;
+      if (g.a.spatial) {
+        const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+        geo.b = b; geo.y = rem / g.a.Wo; geo.x = rem - geo.y * g.a.Wo;
+      }
+      const long sr = seg_src_row(sg, geo, g.a.spatial, m);
+      if (sr >= 0) v = *(const uint4*)((const T*)sg.p + sr * sg.ld + kcol);
+    }
+    *(uint4*)(sA + r * KB + (((c & ~7) | ((c ^ r) & 7)) << 4)) = v;
+  }
+
+  // ---- weight-tile prefetch registers (BN_ x KB bytes over 256 threads)
+  constexpr int WREGS = (BN_ * (BN_ == 128 ? 384 : 768) / 16 + 255) / 256;   // BN 128 <-> KB <= 384, BN 64 <-> KB <= 768
+  uint4 wreg[WREGS];
+  const int wchunks = BN_ * CPRK;
+  auto load_w = [&](int n0) {
+#pragma unroll
+    for (int i = 0; i < WREGS; ++i) {
+      const int id = tid + i * 256;
+      wreg[i] = make_uint4(0, 0, 0, 0);
+      if (id < wchunks) {
+        const int r = id / CPRK, c = id - r * CPRK;
+        if (n0 + r < g.N) wreg[i] = *(const uint4*)((const T*)g.W + (long)(n0 + r) * g.ldw + c * KPL);
+      }
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < WREGS; ++i) {
+      const int id = tid + i * 256;
+      if (id < wchunks) {
+        const int r = id / CPRK, c = id - r * CPRK;
+        *(uint4*)(sW + r * KB + (((c & ~7) | ((c ^ r) & 7)) << 4)) = wreg[i];
+      }
+    }
+  };
+
+  const int ntiles = (g.N + BN_ - 1) / BN_;
+  const int nkb = g.K / MK;
+  load_w(0);
+  for (int jt = 0; jt < ntiles; ++jt) {
+    const int n0 = jt * BN_;
+    store_w();
+    __syncthreads();                                   // A (first pass) and W(jt) visible
+    if (jt + 1 < ntiles && !(flags & (1 << 22))) load_w(n0 + BN_);   // in flight under the MFMAs + epilogue
+    f32x4 acc[2][NSUB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NSUB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < ((flags & (1 << 21)) ? 0 : nkb); ++kb) {
+      const int ch = kb * 4 + fg;
+      uint4 fa[2], fb[NSUB];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wr * 32 + i * 16 + fr;
+        fa[i] = *(const uint4*)(sA + r * KB + (((ch & ~7) | ((ch ^ r) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NSUB; ++j) {
+        const int c = wc * (BN_ / 2) + j * 16 + fr;
+        fb[j] = *(const uint4*)(sW + c * KB + (((ch & ~7) | ((ch ^ c) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) mma16<T>(acc[i][j], fa[i], fb[j]);
+    }
+    __syncthreads();                                   // every wave is done with sW -> reuse it for staging
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sC[(wr * 32 + i * 16 + fg * 4 + r) * ELD + wc * (BN_ / 2) + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    if (flags & SODT_EPI_STATS) {
+      if (tid < BN_ && n0 + tid < g.N) {
+        double s1 = 0.0, s2 = 0.0;
+        const int rmax = (int)((g.M - m0) < AS_BM ? (g.M - m0) : AS_BM);
+        for (int r = 0; r < rmax; ++r) {
+          const float v = sC[r * ELD + tid];
+          s1 += v; s2 += (double)v * v;
         }
-      } else {
-        for (int j = 0; j < KPL; ++j) if (n + j < g.N) v[j] += g.bias[n + j];
+        atomicAdd(g.stats + n0 + tid, s1);
+        atomicAdd(g.stats + g.N + n0 + tid, s2);
       }
     }
-    if (flags & SODT_EPI_AFFINE_SILU) {
-      float sc[KPL], sh[KPL];
-      if (full) {
+    constexpr int CPR = BN_ / KPL;
+    for (int idx = tid; idx < AS_BM * CPR; idx += 256) {
+      const int r = idx / CPR, c = (idx - r * CPR) * KPL;
+      const long m = m0 + r; const int n = n0 + c;
+      if (m >= g.M || n >= g.N) continue;
+      float v[KPL];
 #pragma unroll
-        for (int j = 0; j < KPL; j += 4) {
-          const float4 a4 = *(const float4*)(g.scale + n + j);
-          const float4 b4 = *(const float4*)(g.shift + n + j);
-          sc[j] = a4.x; sc[j + 1] = a4.y; sc[j + 2] = a4.z; sc[j + 3] = a4.w;
-          sh[j] = b4.x; sh[j + 1] = b4.y; sh[j + 2] = b4.z; sh[j + 3] = b4.w;
+      for (int j = 0; j < KPL; j += 4) {
+        const float4 t = *(const float4*)(sC + r * ELD + c + j);
+        v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+      }
+      if (!(flags & (1 << 20))) epi_chunk<T>(g, flags, m, n, v, hw);
+    }
+    __syncthreads();                                   // staging consumed before the next W tile lands
+  }
+}
+
+template <typename T, int BN_>
+int launch_as(const sodt_gemm_args* g, hipStream_t st) {
+  const int KB = g->K * (int)sizeof(T);
+  const int wbytes = BN_ * KB, sbytes = AS_BM * (BN_ + 4) * 4;
+  const int lds = AS_BM * KB + (wbytes > sbytes ? wbytes : sbytes);
+  static int max_set = 0;
+  if (lds > max_set) {
+    if (hipFuncSetAttribute((const void*)gemm_as_kernel<T, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+      return SODT_EINVAL;
+    max_set = 160 * 1024;
+  }
+  const long blocks = ((long)g->M + AS_BM - 1) / AS_BM;
+  hipLaunchKernelGGL((gemm_as_kernel<T, BN_>), dim3((unsigned)blocks), dim3(256), lds, st, *g);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------
+// Persistent weight-stationary variant (the workhorse for K * sizeof(T) <= 384 bytes, i.e. every
+// C = 192 GEMM of stage 1 in bf16).  A workgroup owns ONE 128-column tile of the output for its whole
+// life: the W tile (128 x K) sits in LDS, 64-row blocks of A stream through a single LDS buffer with a
+// register prefetch of the next block (issued before the MFMAs of the current one), and the epilogue
+// runs straight out of the accumulators.  MFMA operands are swapped (A-operand = W rows, B-operand =
+// activation rows) and the W rows are fed in a permuted order so that each lane ends up with 8
+// consecutive output columns of one row -> one 16-byte store per lane, 64 contiguous bytes per row
+// and wave instruction, no LDS staging and one barrier pair per row block.  Workgroups that walk the
+// same row blocks (one per column tile) are placed on one XCD so that A is fetched from HBM once.
+// ---------------------------------------------------------------------------------
+template <typename T, int BN_, bool STATS>
+__global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g, const int teams_per_xcd) {
+  constexpr int KPL = TT<T>::KPL;
+  constexpr int MK = TT<T>::MMA_K;
+  constexpr int NP = BN_ / 64;                 // 32-column "pairs" per wave (2 waves across N)
+  constexpr int AREGS = (AS_BM * 384 / 16 + 255) / 256;   // 6 (KB <= 384)
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  __shared__ sodt_seg sSeg[SODT_MAX_SEG];
+  const int KB = g.K * (int)sizeof(T);
+  const int CPRK = KB >> 4;
+  unsigned char* sW = dsm;                     // [BN][KB] swizzled, resident
+  unsigned char* sA = dsm + BN_ * KB;          // [64][KB] swizzled, one row block
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int hw = g.a.Ho * g.a.Wo;
+  const int flags = g.flags;
+  const int ntiles = (g.N + BN_ - 1) / BN_;
+  // block -> (team, column tile): the ntiles members of a team share an XCD (blockIdx % 8) and walk the same row blocks
+  const int xcd = blockIdx.x & 7, ix = blockIdx.x >> 3;
+  const int team_local = ix / ntiles, jt = ix - team_local * ntiles;
+  if (team_local >= teams_per_xcd) return;
+  const int team = team_local * 8 + xcd, nteams = teams_per_xcd * 8;
+  const int n0 = jt * BN_;
+  const long nrb = ((long)g.M + AS_BM - 1) / AS_BM;
+
+  if (tid == 0) {
+#pragma unroll
+    for (int j = 0; j < SODT_MAX_SEG; ++j) sSeg[j] = g.a.s[j];
+  }
+  // ---- resident W tile
+  for (int id = tid; id < BN_ * CPRK; id += 256) {
+    const int r = id / CPRK, c = id - r * CPRK;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (n0 + r < g.N) v = *(const uint4*)((const T*)g.W + (long)(n0 + r) * g.ldw + c * KPL);
+    *(uint4*)(sW + r * KB + (((c & ~7) | ((c ^ r) & 7)) << 4)) = v;
+  }
+
+  uint4 areg[AREGS];
+  auto load_a = [&](long rb) {
+    const long m0 = rb * AS_BM;
+#pragma unroll
+    for (int i = 0; i < AREGS; ++i) {
+      const int id = tid + i * 256;
+      areg[i] = make_uint4(0, 0, 0, 0);
+      if (id < AS_BM * CPRK) {
+        const int r = id / CPRK, c = id - r * CPRK;
+        const long m = m0 + r;
+        if (m < g.M) {
+          int kcol = c * KPL, si = 0;
+          while (si + 1 < g.a.nseg && kcol >= sSeg[si].klen) { kcol -= sSeg[si].klen; ++si; }
+          const sodt_seg sg = sSeg[si];
+          RowGeo geo; geo.ok = true; geo.b = 0; geo.y = 0; geo.x = 0;
+          if (g.a.spatial) {
+            const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+            geo.b = b; geo.y = rem / g.a.Wo; geo.x = rem - geo.y * g.a.Wo;
+          }
+          const long sr = seg_src_row(sg, geo, g.a.spatial, m);
+          if (sr >= 0) areg[i] = *(const uint4*)((const T*)sg.p + sr * sg.ld + kcol);
         }
-      } else {
-        for (int j = 0; j < KPL; ++j) { sc[j] = (n + j < g.N) ? g.scale[n + j] : 0.f; sh[j] = (n + j < g.N) ? g.shift[n + j] : 0.f; }
-      }
-#pragma unroll
-      for (int j = 0; j < KPL; ++j) {
-        const float a = v[j] * sc[j] + sh[j];
-        v[j] = a * sigmoid_f(a);
       }
     }
-    if (flags & SODT_EPI_DGELU) {
-      float x[KPL];
-      const T* ap = (const T*)g.aux + m * g.ldaux + n;
-      if (full) { unpack<T>(*(const uint4*)ap, x); }
-      else { for (int j = 0; j < KPL; ++j) x[j] = (n + j < g.N) ? to_f(ap[j]) : 0.f; }
+  };
+  auto store_a = [&]() {
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) v[j] *= dgelu_f(x[j]);
+    for (int i = 0; i < AREGS; ++i) {
+      const int id = tid + i * 256;
+      if (id < AS_BM * CPRK) {
+        const int r = id / CPRK, c = id - r * CPRK;
+        *(uint4*)(sA + r * KB + (((c & ~7) | ((c ^ r) & 7)) << 4)) = areg[i];
+      }
     }
-    if (flags & SODT_EPI_RESID) {
-      const long rr = g.rmod > 0 ? (m % g.rmod) : m;
-      float x[KPL];
-      const T* rp = (const T*)g.R + rr * g.ldr + n;
-      if (full) { unpack<T>(*(const uint4*)rp, x); }
-      else { for (int j = 0; j < KPL; ++j) x[j] = (n + j < g.N) ? to_f(rp[j]) : 0.f; }
+  };
+
+  // per-lane column statistics (SODT_EPI_STATS): lane owns columns n0 + wc*BN/2 + p*32 + 8*fg + 0..7
+  float st1[NP][8], st2[NP][8];
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) v[j] += x[j];
-    }
-    long orow = m;
-    if (g.oscatter) {
-      const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
-      const int y = rem / g.a.Wo, x = rem - y * g.a.Wo;
-      orow = ((long)b * g.OH + y * g.omul + g.ody) * g.OW + x * g.omul + g.odx;
-    }
-    if (out32) {
-      float* cp = (float*)g.C + orow * g.ldc + n;
-      for (int j = 0; j < KPL; ++j) if (full || n + j < g.N) cp[j] = v[j];
-    } else {
-      T* cp = (T*)g.C + orow * g.ldc + n;
-      if (full) *(uint4*)cp = pack<T>(v);
-      else for (int j = 0; j < KPL; ++j) if (n + j < g.N) cp[j] = from_f<T>(v[j]);
-      if (flags & SODT_EPI_GELU_DUAL) {
-        float a[KPL];
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) a[j] = gelu_f(v[j]);
-        T* c2 = (T*)g.C2 + orow * g.ldc2 + n;
-        if (full) *(uint4*)c2 = pack<T>(a);
-        else for (int j = 0; j < KPL; ++j) if (n + j < g.N) c2[j] = from_f<T>(a[j]);
+    for (int j = 0; j < 8; ++j) { st1[p][j] = 0.f; st2[p][j] = 0.f; }
+
+  const int nkb = g.K / MK;
+  long rb = team;
+  __syncthreads();                                     // segment table visible
+  if (rb < nrb) load_a(rb);
+  for (; rb < nrb; rb += nteams) {
+    __syncthreads();                                   // previous block's MFMAs are done with sA
+    store_a();
+    __syncthreads();
+    if (rb + nteams < nrb) load_a(rb + nteams);        // in flight under the MFMAs + epilogue
+    f32x4 acc[NP][2][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) acc[p][s2][sm] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < nkb; ++kb) {
+      const int ch = kb * 4 + fg;
+      uint4 fw[NP][2], fx[2];
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int nl = wc * (BN_ / 2) + p * 32 + 8 * (fr >> 2) + 4 * s2 + (fr & 3);   // permuted W row fed as MFMA row fr
+          fw[p][s2] = *(const uint4*)(sW + nl * KB + (((ch & ~7) | ((ch ^ nl) & 7)) << 4));
+        }
+#pragma unroll
+      for (int sm = 0; sm < 2; ++sm) {
+        const int r = wr * 32 + sm * 16 + fr;
+        fx[sm] = *(const uint4*)(sA + r * KB + (((ch & ~7) | ((ch ^ r) & 7)) << 4));
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int sm = 0; sm < 2; ++sm) mma16<T>(acc[p][s2][sm], fw[p][s2], fx[sm]);
+    }
+    // ---- epilogue from registers: lane (fg, fr) holds out[m = .. + fr][n .. n+7]
+    const long m0 = rb * AS_BM;
+#pragma unroll
+    for (int sm = 0; sm < 2; ++sm) {
+      const long m = m0 + wr * 32 + sm * 16 + fr;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int n = n0 + wc * (BN_ / 2) + p * 32 + 8 * fg;
+        if (m < g.M && n < g.N) {
+          if (STATS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float a = acc[p][0][sm][j], b = acc[p][1][sm][j];
+              st1[p][j] += a; st2[p][j] += a * a; st1[p][4 + j] += b; st2[p][4 + j] += b * b;
+            }
+          }
+          if (KPL == 8) {
+            float v[TT<T>::KPL];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = acc[p][0][sm][j]; v[(4 + j) % KPL] = acc[p][1][sm][j]; }
+            epi_chunk<T>(g, flags, m, n, v, hw);
+          } else {
+            float v[TT<T>::KPL];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[p][0][sm][j];
+            epi_chunk<T>(g, flags, m, n, v, hw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[p][1][sm][j];
+            epi_chunk<T>(g, flags, m, n + 4, v, hw);
+          }
+        }
       }
     }
   }
+  if (STATS) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = group16_sum(st1[p][j]), b = group16_sum(st2[p][j]);
+        const int n = n0 + wc * (BN_ / 2) + p * 32 + 8 * fg + j;
+        if (fr == 0 && n < g.N) {
+          atomicAdd(g.stats + n, (double)a);
+          atomicAdd(g.stats + g.N + n, (double)b);
+        }
+      }
+  }
+}
+
+template <typename T, int BN_, bool STATS>
+int launch_bs(const sodt_gemm_args* g, hipStream_t st) {
+  const int KB = g->K * (int)sizeof(T);
+  const int lds = (BN_ + AS_BM) * KB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_bs_kernel<T, BN_, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+      return SODT_EINVAL;
+    attr_set = true;
+  }
+  const int ntiles = (g->N + BN_ - 1) / BN_;
+  const long nrb = ((long)g->M + AS_BM - 1) / AS_BM;
+  const int per_cu = lds <= 76 * 1024 ? 2 : 1;
+  int teams_per_xcd = (32 * per_cu) / ntiles;          // 32 CUs per XCD
+  if (teams_per_xcd < 1) teams_per_xcd = 1;
+  const long max_teams = (nrb + 7) / 8;
+  if (teams_per_xcd > max_teams) teams_per_xcd = (int)max_teams;
+  const int blocks = teams_per_xcd * ntiles * 8;
+  hipLaunchKernelGGL((gemm_bs_kernel<T, BN_, STATS>), dim3(blocks), dim3(256), lds, st, *g, teams_per_xcd);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
 // ---------------------------------------------------------------------------------
@@ -452,6 +833,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const sodt_gemm_tn_args
     }
 }
 
+int g_force_tiled = 0;   // test hook: sodt_gemm_set_variant(1) forces the K-loop kernel, (2) the A-stationary one
+int g_variant = 0;
+
 bool aspec_ok(const sodt_aspec& a, int K, int kpl) {
   if (a.nseg < 1 || a.nseg > SODT_MAX_SEG) return false;
   long tot = 0;
@@ -483,6 +867,27 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
   if ((g->flags & SODT_EPI_STATS) && !g->stats) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_AFFINE_SILU) && (!g->scale || !g->shift || ((((uintptr_t)g->scale) | ((uintptr_t)g->shift)) & 15))) return SODT_EINVAL;
   if (g->oscatter && !g->a.spatial) return SODT_EINVAL;
+  // short contraction -> A-stationary kernel (row bytes a multiple of 128 so the XOR swizzle stays in-row)
+  {
+    const int es = dtype == SODT_BF16 ? 2 : 4;
+    const int KB = g->K * es;
+    bool seg_ok = true;
+    for (int i = 0; i < g->a.nseg; ++i) seg_ok = seg_ok && ((g->a.s[i].klen * es) % 16 == 0);
+    if (!(g->flags & SODT_EPI_DETECT) && (KB % 128) == 0 && KB <= 384 && seg_ok && !g_force_tiled) {
+      hipStream_t s_ = (hipStream_t)st;
+      const int kplv = dtype == SODT_BF16 ? 8 : 4;
+      const bool bs_ok = (g->N % kplv) == 0 && (g->flags & SODT_EPI_OUT_F32) == 0 && g_variant != 2;
+      if (bs_ok) {
+        const bool stt = (g->flags & SODT_EPI_STATS) != 0;
+        if (dtype == SODT_BF16) return stt ? launch_bs<bf16, 128, true>(g, s_) : launch_bs<bf16, 128, false>(g, s_);
+        if (dtype == SODT_F32) return stt ? launch_bs<float, 128, true>(g, s_) : launch_bs<float, 128, false>(g, s_);
+        return SODT_EINVAL;
+      }
+      if (dtype == SODT_BF16) return KB <= 384 ? launch_as<bf16, 128>(g, s_) : launch_as<bf16, 64>(g, s_);
+      if (dtype == SODT_F32) return KB <= 384 ? launch_as<float, 128>(g, s_) : launch_as<float, 64>(g, s_);
+      return SODT_EINVAL;
+    }
+  }
   const long tiles = ((long)(g->M + BM - 1) / BM) * ((g->N + BN - 1) / BN);
   if (tiles > 0x7fffffffL) return SODT_EINVAL;
   dim3 grid((unsigned)tiles), block(256);
@@ -492,6 +897,12 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
     hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, (hipStream_t)st, *g);
   } else return SODT_EINVAL;
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+extern "C" int sodt_gemm_set_variant(int force_tiled) {
+  g_force_tiled = force_tiled == 1;
+  g_variant = force_tiled;
+  return SODT_OK;
 }
 
 extern "C" int sodt_gemm_tn(const sodt_gemm_tn_args* g, int dtype, sodt_stream_t st) {

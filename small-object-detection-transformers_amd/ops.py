@@ -123,7 +123,7 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
             gelu_out: Optional[torch.Tensor] = None, dgelu_aux: Optional[torch.Tensor] = None,
             stats: Optional[torch.Tensor] = None, affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
             out_f32: bool = False, detect: Optional[Tuple[int, int, int]] = None,
-            oscatter: Optional[Tuple[int, int, int, int, int]] = None, w_off: int = 0) -> None:
+            oscatter: Optional[Tuple[int, int, int, int, int]] = None, w_off: int = 0, debug_flags: int = 0) -> None:
     """out[M][N] = epilogue(concat_k(segs) @ W[N][K]^T); see SODT_EPI_* in include/sodt_hip.h."""
     g = L.GemmArgs()
     _fill_aspec(g.a, segs, spatial)
@@ -164,7 +164,7 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
     if oscatter is not None:
         g.oscatter = 1
         g.omul, g.ody, g.odx, g.OH, g.OW = oscatter
-    g.M, g.N, g.K, g.flags = M, N, K, flags
+    g.M, g.N, g.K, g.flags = M, N, K, flags | debug_flags
     _launch("sodt_gemm_nt", C.byref(g), dt_code(W))
 
 
@@ -280,6 +280,11 @@ def cast(src, dst, n):
 
 def batch_sum(d, out, B, RC):
     _launch("sodt_batch_sum", _p(d), _p(out), B, RC, dt_code(d))
+
+
+def gemm_set_variant(v) -> None:
+    """0/False: automatic; 1/True: force the K-loop tile kernel; 2: force the A-stationary kernel (tests)."""
+    _lib.sodt_gemm_set_variant(int(v))
 
 
 def version() -> str:

@@ -30,10 +30,20 @@ def rnd(shape, dev, dt, seed, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev).to(dt)
 
 
+@pytest.fixture(params=["auto", "tiled", "astat"])
+def variant(request, ops):
+    """NT GEMMs run through all three kernels: auto (weight-stationary persistent for short K), the K-loop
+    tile kernel, and the A-stationary kernel."""
+    ops.gemm_set_variant({"auto": 0, "tiled": 1, "astat": 2}[request.param])
+    yield request.param
+    ops.gemm_set_variant(False)
+
+
 # ------------------------------------------------------------------ GEMM NT
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 576, 192), (130, 39, 128), (512, 192, 768), (128, 256, 48)])
-def test_gemm_nt_plain_bias_resid(ops, dev, dt, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 576, 192), (130, 39, 128), (512, 192, 768), (128, 256, 48),
+                                   (1000, 200, 384), (77, 768, 192)])
+def test_gemm_nt_plain_bias_resid(ops, dev, dt, M, N, K, variant):
     A = rnd((M, K), dev, dt, 1)
     W = rnd((N, K), dev, dt, 2, 1 / math.sqrt(K))
     bias = rnd((N,), dev, torch.float32, 3)
@@ -50,7 +60,7 @@ def test_gemm_nt_plain_bias_resid(ops, dev, dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_nt_gelu_dgelu_rmod(ops, dev, dt):
+def test_gemm_nt_gelu_dgelu_rmod(ops, dev, dt, variant):
     M, N, K = 384, 256, 192
     A = rnd((M, K), dev, dt, 1)
     W = rnd((N, K), dev, dt, 2, 1 / math.sqrt(K))
@@ -74,7 +84,7 @@ def test_gemm_nt_gelu_dgelu_rmod(ops, dev, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_nt_stats_affine_detect(ops, dev, dt):
+def test_gemm_nt_stats_affine_detect(ops, dev, dt, variant):
     M, N, K = 1000, 128, 256
     A = rnd((M, K), dev, dt, 1)
     W = rnd((N, K), dev, dt, 2, 1 / math.sqrt(K))
@@ -106,7 +116,7 @@ def _nhwc(x):   # (B,C,H,W) -> token-major (B*H*W, C)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_nt_conv_taps(ops, dev, dt):
+def test_gemm_nt_conv_taps(ops, dev, dt, variant):
     """2x2 conv with right/bottom zero pad (Mlp conv variant), 3x3 same conv, and their input gradients."""
     B, H, W, Ci, Co = 2, 12, 20, 64, 128
     x = rnd((B, Ci, H, W), dev, dt, 1)
@@ -141,7 +151,7 @@ def test_gemm_nt_conv_taps(ops, dev, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_nt_merge_upsample_scatter(ops, dev, dt):
+def test_gemm_nt_merge_upsample_scatter(ops, dev, dt, variant):
     B, H, W, Cc = 2, 8, 12, 64
     x = rnd((B, H, W, Cc), dev, dt, 1)
     xt = x.reshape(-1, Cc)
