@@ -29,6 +29,8 @@ struct AttnGeo {
 };
 
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+#define SODT_LOG2E 1.4426950408889634f
 
 // token row + mask region of window-local token n of window (b, wy, wx)
 __device__ __forceinline__ void win_token(const AttnGeo& g, int b, int wy, int wx, int n, int& row, int& rid,
@@ -302,7 +304,35 @@ __global__ __launch_bounds__(256) void attn_dq_finish_kernel(float* __restrict__
   }
 }
 
-template <typename T, int HD, int NW>
+// issue the global loads of one 8x8 window (Q, K, V, dO chunks of this thread + its lane's lse) into registers
+template <typename T, int HD, int NW, int NPF>
+__device__ __forceinline__ void attn_prefetch(const AttnGeo& g, const T* __restrict__ qkv, const T* __restrict__ d_out,
+                                              const float* __restrict__ lse, int item, int hg, int head, int tid, int lane,
+                                              uint4 (&pq)[NPF], uint4 (&pk)[NPF], uint4 (&pv)[NPF], uint4 (&pdo)[NPF], float& plse) {
+  using L = Lay<T, HD>;
+  constexpr int KPL = L::KPL, NT = NW * 64, CPR = NW * L::DCH;
+  const int C3 = 3 * g.C;
+  int t_ = item;
+  const int wx_ = t_ % g.nwx; t_ /= g.nwx;
+  const int wy_ = t_ % g.nwy; const int b_ = t_ / g.nwy;
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int idx = tid + i * NT;
+    const int r = idx / CPR, cc = idx - r * CPR;
+    int row, rid, iy, ix;
+    win_token(g, b_, wy_, wx_, r, row, rid, iy, ix);
+    const T* src = qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL;
+    pq[i] = *(const uint4*)(src);
+    pk[i] = *(const uint4*)(src + g.C);
+    pv[i] = *(const uint4*)(src + 2 * g.C);
+    pdo[i] = *(const uint4*)(d_out + (long)row * g.C + (hg * NW) * HD + cc * KPL);
+  }
+  int row, rid, iy, ix;
+  win_token(g, b_, wy_, wx_, lane, row, rid, iy, ix);
+  plse = lse[(long)row * g.heads + head];
+}
+
+template <typename T, int HD, int NW, bool FAST>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
                                                           const T* __restrict__ d_out, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, T* __restrict__ dqkv,
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
   const int L2 = 2 * g.ws - 1;
   const int R = g.ws >= 64 ? 1 : 64 / g.ws;      // window rows per 64-token tile
   const int LT = (2 * R - 1) * L2;
-  const bool single = g.nqt == 1;
+  const bool single = FAST || g.nqt == 1;
   const float scale = rsqrtf((float)HD);
   const float* bt = bias_t + (long)head * L2 * L2;
   constexpr int CPR = NW * L::DCH;
@@ -351,6 +381,37 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
     for (int c = 0; c < 4; ++c) dbacc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nitems = nwin_total * g.nqt;
+  // Single-tile windows (8x8: stages 1 and 2): the next window's Q/K/V/dO chunks and lse are prefetched into
+  // registers while the current window is computed, so no global-memory latency is exposed inside the loop.
+  constexpr bool pf = FAST;                       // FAST <=> one 64-token tile per window and 4*DCH <= 16 registers
+  constexpr int NPF = FAST ? L::DCH : 1;          // chunks per thread and tensor (64*CPR / NT)
+  uint4 pq[NPF], pk[NPF], pv[NPF], pdo[NPF];
+  float plse = 0.f;
+  // per-lane bias values (x log2 e) of its 64 (q, key) positions: identical for every window of this head
+  float bias2[4][4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias2[a][c][r] = 0.f;
+  if constexpr (pf) {
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qn = ms * 16 + fg * 4 + r;
+        const int qiy = qn / g.ws, qix = qn - qiy * g.ws;
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) {
+          const int kn = ns * 16 + fr;
+          const int kiy_ = kn / g.ws, kix_ = kn - kiy_ * g.ws;
+          bias2[ms][ns][r] = bt[(qiy - kiy_ + g.ws - 1) * L2 + (qix - kix_ + g.ws - 1)] * SODT_LOG2E;
+        }
+      }
+    if ((int)blockIdx.x < nitems)
+      attn_prefetch<T, HD, NW, NPF>(g, qkv, d_out, lse, blockIdx.x, hg, head, tid, lane, pq, pk, pv, pdo, plse);
+  }
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     int t = item;
     const int kt = t % g.nqt; t /= g.nqt;
@@ -363,13 +424,29 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
       win_token(g, b, wy, wx, kt * 64 + tid, row, rid, iy, ix);
       sTokK[tid] = row; sGeoK[tid][0] = (short)iy; sGeoK[tid][1] = (short)ix; sGeoK[tid][2] = (short)rid;
     }
+    if constexpr (pf) {
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx / CPR, cc = idx - r * CPR;
+        const int h = cc / L::DCH, dc = cc - h * L::DCH;
+        const int off = (h * 64 + r) * L::QROW + dc * 16;
+        *(uint4*)(sQ + off) = pq[i]; *(uint4*)(sK + off) = pk[i]; *(uint4*)(sV + off) = pv[i]; *(uint4*)(sDO + off) = pdo[i];
+      }
+      sLse[w][lane] = plse * SODT_LOG2E;
+    }
     __syncthreads();
-    for (int idx = tid; idx < 64 * CPR; idx += NT) {
-      const int r = idx / CPR, cc = idx - r * CPR;
-      const int h = cc / L::DCH, dc = cc - h * L::DCH;
-      const T* src = qkv + (long)sTokK[r] * C3 + (hg * NW) * HD + cc * KPL;
-      *(uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(src + g.C);
-      *(uint4*)(sV + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(src + 2 * g.C);
+    if constexpr (pf) {
+      if (item + (int)gridDim.x < nitems)
+        attn_prefetch<T, HD, NW, NPF>(g, qkv, d_out, lse, item + gridDim.x, hg, head, tid, lane, pq, pk, pv, pdo, plse);
+    } else {
+      for (int idx = tid; idx < 64 * CPR; idx += NT) {
+        const int r = idx / CPR, cc = idx - r * CPR;
+        const int h = cc / L::DCH, dc = cc - h * L::DCH;
+        const T* src = qkv + (long)sTokK[r] * C3 + (hg * NW) * HD + cc * KPL;
+        *(uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(src + g.C);
+        *(uint4*)(sV + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(src + 2 * g.C);
+      }
     }
     f32x4 dk[4][HD / 16], dv[4][HD / 16];
 #pragma unroll
@@ -386,21 +463,21 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
       }
       __syncthreads();
       const int dyoff = (qt - kt) * R;
-      {
+      if constexpr (!pf) {
         for (int i = lane; i < LT; i += 64) {
           const int a = i / L2, c = i - a * L2;
           const int gy = a - (R - 1) + dyoff + g.ws - 1;
           sBias[w][i] = (gy >= 0 && gy < L2) ? bt[gy * L2 + c] : 0.f;
         }
         const long tq = sTokQ[lane];
-        sLse[w][lane] = lse[tq * g.heads + head];
+        sLse[w][lane] = lse[tq * g.heads + head] * SODT_LOG2E;
         sDelta[w][lane] = single ? 0.f : delta[tq * g.heads + head];
-      }
-      for (int idx = tid; idx < 64 * CPR; idx += NT) {
-        const int r = idx / CPR, cc = idx - r * CPR;
-        const int h = cc / L::DCH, dc = cc - h * L::DCH;
-        *(uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(qkv + (long)sTokQ[r] * C3 + (hg * NW) * HD + cc * KPL);
-        *(uint4*)(sDO + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(d_out + (long)sTokQ[r] * g.C + (hg * NW) * HD + cc * KPL);
+        for (int idx = tid; idx < 64 * CPR; idx += NT) {
+          const int r = idx / CPR, cc = idx - r * CPR;
+          const int h = cc / L::DCH, dc = cc - h * L::DCH;
+          *(uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(qkv + (long)sTokQ[r] * C3 + (hg * NW) * HD + cc * KPL);
+          *(uint4*)(sDO + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(d_out + (long)sTokQ[r] * g.C + (hg * NW) * HD + cc * KPL);
+        }
       }
       __syncthreads();
 
@@ -410,6 +487,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
       for (int ns = 0; ns < 4; ++ns) {
         kiy[ns] = sGeoK[ns * 16 + fr][0]; kix[ns] = sGeoK[ns * 16 + fr][1]; krid[ns] = sGeoK[ns * 16 + fr][2];
       }
+      // only windows in the last window row / column see more than one mask region (backbone_vit.py:1061-1072)
+      const bool msk = g.shift > 0 && (wy == g.nwy - 1 || wx == g.nwx - 1);
+      const float scale2 = scale * SODT_LOG2E;
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms) {
         f32x4 s[4], dp[4];
@@ -430,16 +510,21 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qn = ms * 16 + fg * 4 + r;
-          const int qiy = sGeoQ[qn][0], qix = sGeoQ[qn][1], qrid = sGeoQ[qn][2];
           const float lq = sLse[w][qn];
+          int qiy = 0, qix = 0, qrid = 0;
+          if (!pf || msk) { qiy = sGeoQ[qn][0]; qix = sGeoQ[qn][1]; qrid = sGeoQ[qn][2]; }
+          (void)qiy; (void)qix;
           float dl = 0.f;
 #pragma unroll
           for (int ns = 0; ns < 4; ++ns) {
-            float v = s[ns][r] * scale + sBias[w][(qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1)];
-            if (qrid != krid[ns]) v += -100.0f;
-            const float p = fast_exp(v - lq);
+            float bv;
+            if constexpr (pf) bv = bias2[ms][ns][r];
+            else bv = sBias[w][(qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1)] * SODT_LOG2E;
+            float v = fmaf(s[ns][r], scale2, bv);
+            if (msk && qrid != krid[ns]) v += -100.0f * SODT_LOG2E;
+            const float p = fast_exp2(v - lq);
             s[ns][r] = p;
-            dl += p * dp[ns][r];
+            dl = fmaf(p, dp[ns][r], dl);
           }
           if (single) dl = group16_sum(dl);
           else dl = sDelta[w][qn];
@@ -615,8 +700,13 @@ int launch_bwd(const void* qkv, const float* bias_t, const void* out, const void
   }
   const int nitems = nwin * g.nqt;
   int gx = nitems < 1024 ? nitems : 1024;
-  hipLaunchKernelGGL((attn_bwd_kernel<T, HD, NW>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
-                     (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin);
+  constexpr bool PFOK = (4 * Lay<T, HD>::DCH <= 16);
+  if (PFOK && g.nqt == 1)
+    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, NW, PFOK>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
+                       (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin);
+  else
+    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, NW, false>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
+                       (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin);
   if (g.nqt > 1)
     hipLaunchKernelGGL((attn_dq_finish_kernel<T>), dim3(1024), dim3(256), 0, st, dq_acc, (T*)dqkv, M, g.C);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;

@@ -715,10 +715,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const sodt_gemm_tn_args
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int ntk = (g.K + 127) / 128;
-  const int tk = blockIdx.x % ntk, tn = blockIdx.x / ntk;
+  // all tiles of one M-slice are adjacent logical blocks -> one XCD: the slice's dY / X rows are fetched
+  // from HBM once and re-read by the other tiles out of that XCD's L2
+  const int ntiles_ = ntk * ((g.N + 127) / 128);
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lid / ntiles_, tile_ = lid - split * ntiles_;
+  const int tk = tile_ % ntk, tn = tile_ / ntk;
   const int n0 = tn * 128, k0 = tk * 128;
   const long rows_per = (((g.M + g.splits - 1) / g.splits) + BMS - 1) / BMS * BMS;
-  const long mbeg = (long)blockIdx.y * rows_per;
+  const long mbeg = (long)split * rows_per;
   const long mend = (mbeg + rows_per < g.M) ? (mbeg + rows_per) : g.M;
   if (mbeg >= mend) return;
 
@@ -912,7 +917,7 @@ extern "C" int sodt_gemm_tn(const sodt_gemm_tn_args* g, int dtype, sodt_stream_t
   if ((g->ldy % kpl) || g->ldy < (g->N + kpl - 1) / kpl * kpl || (((uintptr_t)g->dY) & 15)) return SODT_EINVAL;
   if (g->kperm_t > 1 && (g->kperm_c <= 0 || g->kperm_c * g->kperm_t != g->K)) return SODT_EINVAL;
   const int tiles = ((g->N + 127) / 128) * ((g->K + 127) / 128);
-  dim3 grid(tiles, g->splits), block(256);
+  dim3 grid(tiles * g->splits), block(256);
   if (dtype == SODT_BF16) {
     hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, block, 0, (hipStream_t)st, *g);
   } else if (dtype == SODT_F32) {
