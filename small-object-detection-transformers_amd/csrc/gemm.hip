@@ -18,6 +18,9 @@
 
 namespace {
 
+int g_force_tiled = 0;   // test hook: sodt_gemm_set_variant(1) forces the K-loop / 128x128 TN kernels, (2) the A-stationary NT kernel
+int g_variant = 0;
+
 constexpr int BM = 128, BN = 128, ROWB = 128;          // ROWB: bytes per LDS row per K-step
 constexpr int STAGE_BYTES = BM * ROWB;                 // 16 KiB per operand per stage
 constexpr int EPI_LD = 132;                            // padded f32 row of the staged accumulator tile
@@ -555,6 +558,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g,
 #pragma unroll
     for (int j = 0; j < 8; ++j) { st1[p][j] = 0.f; st2[p][j] = 0.f; }
 
+  // epilogue operands of this lane's fixed columns: bias in registers for the whole kernel; the residual / gelu'
+  // source chunks of the current row block are fetched BEFORE its MFMAs so their latency is never exposed
+  constexpr int NCH = 8 / KPL;                         // 16-byte chunks per 8 output columns
+  float breg[NP][8];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int n = n0 + wc * (BN_ / 2) + p * 32 + 8 * fg + j;
+      breg[p][j] = ((flags & SODT_EPI_BIAS) && n < g.N) ? g.bias[n] : 0.f;
+    }
+  uint4 rres[2][NP][NCH], raux[2][NP][NCH];
+  const int eflags = flags & ~(SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_DGELU);
+
   const int nkb = g.K / MK;
   long rb = team;
   __syncthreads();                                     // segment table visible
@@ -564,6 +581,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g,
     store_a();
     __syncthreads();
     if (rb + nteams < nrb) load_a(rb + nteams);        // in flight under the MFMAs + epilogue
+    if (flags & (SODT_EPI_RESID | SODT_EPI_DGELU)) {
+#pragma unroll
+      for (int sm = 0; sm < 2; ++sm) {
+        const long m = rb * AS_BM + wr * 32 + sm * 16 + fr;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int n = n0 + wc * (BN_ / 2) + p * 32 + 8 * fg;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            rres[sm][p][c] = make_uint4(0, 0, 0, 0);
+            raux[sm][p][c] = make_uint4(0, 0, 0, 0);
+            if (m < g.M && n + c * KPL < g.N) {
+              if (flags & SODT_EPI_RESID) {
+                const long rr = g.rmod > 0 ? (m % g.rmod) : m;
+                rres[sm][p][c] = *(const uint4*)((const T*)g.R + rr * g.ldr + n + c * KPL);
+              }
+              if (flags & SODT_EPI_DGELU) raux[sm][p][c] = *(const uint4*)((const T*)g.aux + m * g.ldaux + n + c * KPL);
+            }
+          }
+        }
+      }
+    }
     f32x4 acc[NP][2][2];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -609,19 +648,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g,
               st1[p][j] += a; st2[p][j] += a * a; st1[p][4 + j] += b; st2[p][4 + j] += b * b;
             }
           }
-          if (KPL == 8) {
+          float v8[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v8[j] = acc[p][0][sm][j] + breg[p][j]; v8[4 + j] = acc[p][1][sm][j] + breg[p][4 + j]; }
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
             float v[TT<T>::KPL];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = acc[p][0][sm][j]; v[(4 + j) % KPL] = acc[p][1][sm][j]; }
-            epi_chunk<T>(g, flags, m, n, v, hw);
-          } else {
-            float v[TT<T>::KPL];
+            for (int j = 0; j < KPL; ++j) v[j] = v8[c * KPL + j];
+            if (flags & SODT_EPI_DGELU) {
+              float x[TT<T>::KPL];
+              unpack<T>(raux[sm][p][c], x);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[p][0][sm][j];
-            epi_chunk<T>(g, flags, m, n, v, hw);
+              for (int j = 0; j < KPL; ++j) v[j] *= dgelu_f(x[j]);
+            }
+            if (flags & SODT_EPI_RESID) {
+              float x[TT<T>::KPL];
+              unpack<T>(rres[sm][p][c], x);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[p][1][sm][j];
-            epi_chunk<T>(g, flags, m, n + 4, v, hw);
+              for (int j = 0; j < KPL; ++j) v[j] += x[j];
+            }
+            if (n + c * KPL < g.N) epi_chunk<T>(g, eflags, m, n + c * KPL, v, hw);
           }
         }
       }
@@ -838,8 +885,190 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const sodt_gemm_tn_args
     }
 }
 
-int g_force_tiled = 0;   // test hook: sodt_gemm_set_variant(1) forces the K-loop kernel, (2) the A-stationary one
-int g_variant = 0;
+// ---------------------------------------------------------------------------------
+// TN, large tile: 256(n) x 192(k) per workgroup of 8 waves (4 x 2, 64 x 96 per wave = 4 x 6 MFMA tiles).
+// The weight-gradient GEMMs are bound by how often dY and X are re-read (once per column / row tile of
+// dW): with K = 192 (every C = 192 layer) X is read once per n-tile and dY exactly once, half the bytes
+// of the 128 x 128 kernel above.  Same transposed-operand reads, same double-buffered register prefetch.
+// ---------------------------------------------------------------------------------
+template <typename T> struct TN2Geo;
+template <> struct TN2Geo<bf16> { static constexpr int BMS = 64, YROW = 256 * 2 + 16, XROW = 192 * 2 + 16; };
+template <> struct TN2Geo<float> { static constexpr int BMS = 32, YROW = 256 * 4 + 16, XROW = 192 * 4 + 16; };
+
+template <typename T>
+__device__ __forceinline__ uint4 tn2_frag(const unsigned char* tile, int rowbytes, int kb, int col0, int lane);
+template <>
+__device__ __forceinline__ uint4 tn2_frag<bf16>(const unsigned char* tile, int rowbytes, int kb, int col0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned char* a = tile + (kb * 32 + 8 * g + q) * rowbytes + (col0 + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  union { s16x4 v; uint2 u; } lo, hi;
+  lo.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  hi.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * rowbytes));
+  return make_uint4(lo.u.x, lo.u.y, hi.u.x, hi.u.y);
+}
+template <>
+__device__ __forceinline__ uint4 tn2_frag<float>(const unsigned char* tile, int rowbytes, int kb, int col0, int lane) {
+  const unsigned char* a = tile + (kb * 16 + 4 * (lane >> 4)) * rowbytes + (col0 + (lane & 15)) * 4;
+  uint4 r;
+  r.x = *(const uint32_t*)(a);
+  r.y = *(const uint32_t*)(a + rowbytes);
+  r.z = *(const uint32_t*)(a + 2 * rowbytes);
+  r.w = *(const uint32_t*)(a + 3 * rowbytes);
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const sodt_gemm_tn_args g) {
+  constexpr int KPL = TT<T>::KPL;
+  constexpr int BMS = TN2Geo<T>::BMS, YROW = TN2Geo<T>::YROW, XROW = TN2Geo<T>::XROW;
+  constexpr int YT = BMS * YROW, XT = BMS * XROW;
+  constexpr int YCPR = 256 / KPL, XCPR = 192 / KPL;             // 16-byte chunks per tile row
+  constexpr int NY = BMS * YCPR / 512, NX = BMS * XCPR / 512;   // chunks per thread: 4 and 3
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  __shared__ sodt_seg sSeg[SODT_MAX_SEG];
+  unsigned char* sY = dsm;               // [2][YT]
+  unsigned char* sX = dsm + 2 * YT;      // [2][XT]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;                        // 4 waves over n, 2 over k
+  if (tid == 0) {
+#pragma unroll
+    for (int j = 0; j < SODT_MAX_SEG; ++j) sSeg[j] = g.x.s[j];
+  }
+  const int ntk = (g.K + 191) / 192;
+  const int ntiles_ = ntk * ((g.N + 255) / 256);
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lid / ntiles_, tile_ = lid - split * ntiles_;
+  const int tk = tile_ % ntk, tn = tile_ / ntk;
+  const int n0 = tn * 256, k0 = tk * 192;
+  const long rows_per = (((g.M + g.splits - 1) / g.splits) + BMS - 1) / BMS * BMS;
+  const long mbeg = (long)split * rows_per;
+  const long mend = (mbeg + rows_per < g.M) ? (mbeg + rows_per) : g.M;
+  __syncthreads();
+  if (mbeg >= mend) return;
+  const bool wave_live = (n0 + wr * 64 < g.N) && (k0 + wc * 96 < g.K);
+  const int hw = g.x.Ho * g.x.Wo;
+
+  // fixed per-thread chunk columns
+  int yrow[NY], ych[NY], xrow[NX], xoff[NX], xsi[NX];
+#pragma unroll
+  for (int i = 0; i < NY; ++i) { const int id = tid + i * 512; yrow[i] = id / YCPR; ych[i] = id - yrow[i] * YCPR; }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int id = tid + i * 512;
+    xrow[i] = id / XCPR;
+    const int ch = id - xrow[i] * XCPR;
+    int kcol = k0 + ch * KPL, si = 0;
+    xsi[i] = -1; xoff[i] = ch;       // xoff keeps the chunk index in its low bits until resolved below
+    if (kcol < g.K) {
+      while (si + 1 < g.x.nseg && kcol >= sSeg[si].klen) { kcol -= sSeg[si].klen; ++si; }
+      xsi[i] = si; 
+    }
+    xoff[i] = (ch << 16) | (kcol & 0xffff);
+  }
+
+  uint4 ry[NY], rx[NX];
+  auto load_regs = [&](long mb) {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const long m = mb + yrow[i];
+      const int col = n0 + ych[i] * KPL;
+      ry[i] = make_uint4(0, 0, 0, 0);
+      if (m < mend && col < g.N) ry[i] = *(const uint4*)((const T*)g.dY + m * g.ldy + col);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const long m = mb + xrow[i];
+      rx[i] = make_uint4(0, 0, 0, 0);
+      if (m < mend && xsi[i] >= 0) {
+        const sodt_seg sg = sSeg[xsi[i]];
+        RowGeo r; r.ok = true; r.b = 0; r.y = 0; r.x = 0;
+        if (g.x.spatial) {
+          const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+          r.b = b; r.y = rem / g.x.Wo; r.x = rem - r.y * g.x.Wo;
+        }
+        const long sr = seg_src_row(sg, r, g.x.spatial, m);
+        if (sr >= 0) rx[i] = *(const uint4*)((const T*)sg.p + sr * sg.ld + (xoff[i] & 0xffff));
+      }
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) *(uint4*)(sY + buf * YT + yrow[i] * YROW + ych[i] * 16) = ry[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) *(uint4*)(sX + buf * XT + xrow[i] * XROW + (xoff[i] >> 16) * 16) = rx[i];
+  };
+
+  f32x4 acc[4][6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool do_bias = (g.dbias != nullptr) && (tk == 0) && tid < 256 && (n0 + tid < g.N);
+
+  const int nsteps = (int)((mend - mbeg + BMS - 1) / BMS);
+  load_regs(mbeg);
+  store_lds(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_regs(mbeg + (long)(s + 1) * BMS);
+    const unsigned char* ty = sY + buf * YT;
+    const unsigned char* tx = sX + buf * XT;
+    if (wave_live) {
+#pragma unroll
+      for (int kb = 0; kb < BMS / TT<T>::MMA_K; ++kb) {
+        uint4 fa[4], fb[6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = tn2_frag<T>(ty, YROW, kb, wr * 64 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) fb[j] = tn2_frag<T>(tx, XROW, kb, wc * 96 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) mma16<T>(acc[i][j], fa[i], fb[j]);
+      }
+    }
+    if (do_bias) {
+      for (int r = 0; r < BMS; ++r) bsum += to_f(*(const T*)(ty + r * YROW + tid * sizeof(T)));
+    }
+    if (s + 1 < nsteps) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+  if (do_bias) atomicAdd(g.dbias + n0 + tid, bsum);
+  if (!wave_live) return;
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int k = k0 + wc * 96 + j * 16 + fr;
+      if (k >= g.K) continue;
+      int kk = k;
+      if (g.kperm_t > 1) kk = (k % g.kperm_c) * g.kperm_t + k / g.kperm_c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wr * 64 + i * 16 + fg * 4 + r;
+        if (n < g.N) atomicAdd(g.dW + (long)n * g.lddw + kk, acc[i][j][r]);
+      }
+    }
+}
+
+template <typename T>
+int launch_tn2(const sodt_gemm_tn_args* g, hipStream_t st) {
+  constexpr int lds = 2 * TN2Geo<T>::BMS * (TN2Geo<T>::YROW + TN2Geo<T>::XROW);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_tn2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+      return SODT_EINVAL;
+    attr_set = true;
+  }
+  const int tiles = ((g->N + 255) / 256) * ((g->K + 191) / 192);
+  hipLaunchKernelGGL((gemm_tn2_kernel<T>), dim3(tiles * g->splits), dim3(512), lds, st, *g);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
 
 bool aspec_ok(const sodt_aspec& a, int K, int kpl) {
   if (a.nseg < 1 || a.nseg > SODT_MAX_SEG) return false;
@@ -916,6 +1145,11 @@ extern "C" int sodt_gemm_tn(const sodt_gemm_tn_args* g, int dtype, sodt_stream_t
   if (!aspec_ok(g->x, g->K, kpl)) return SODT_EINVAL;
   if ((g->ldy % kpl) || g->ldy < (g->N + kpl - 1) / kpl * kpl || (((uintptr_t)g->dY) & 15)) return SODT_EINVAL;
   if (g->kperm_t > 1 && (g->kperm_c <= 0 || g->kperm_c * g->kperm_t != g->K)) return SODT_EINVAL;
+  if (!g_force_tiled && (g->N <= 192 || g->K <= 192)) {   // short side <= 192: the 256 x 192 tile reads each operand (almost) once
+    if (dtype == SODT_BF16) return launch_tn2<bf16>(g, (hipStream_t)st);
+    if (dtype == SODT_F32) return launch_tn2<float>(g, (hipStream_t)st);
+    return SODT_EINVAL;
+  }
   const int tiles = ((g->N + 127) / 128) * ((g->K + 127) / 128);
   dim3 grid(tiles * g->splits), block(256);
   if (dtype == SODT_BF16) {

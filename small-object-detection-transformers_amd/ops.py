@@ -169,8 +169,13 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
 
 
 def tn_splits(M: int, N: int, K: int) -> int:
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    return max(1, min(M // 256 if M >= 256 else 1, (1536 + tiles - 1) // tiles))
+    """M-slices per dW tile so that the grid is one full round of workgroups (no tail): 256 x 192 tiles at one
+    workgroup per CU when the short side is <= 192, 128 x 128 tiles at two per CU otherwise (csrc/gemm.hip)."""
+    if N <= 192 or K <= 192:
+        tiles, slots = ((N + 255) // 256) * ((K + 191) // 192), 256
+    else:
+        tiles, slots = ((N + 127) // 128) * ((K + 127) // 128), 1536
+    return max(1, min(M // 256 if M >= 256 else 1, max(1, slots // tiles)))
 
 
 def gemm_tn(dY: torch.Tensor, segs: Sequence[SegSpec], dW: torch.Tensor, M: int, N: int, K: int, *,

@@ -195,7 +195,7 @@ def test_gemm_nt_merge_upsample_scatter(ops, dev, dt, variant):
 # ------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K,splits", [(512, 128, 128, 1), (1000, 192, 192, 3), (4096, 576, 192, None), (700, 48, 128, 2)])
-def test_gemm_tn(ops, dev, dt, M, N, K, splits):
+def test_gemm_tn(ops, dev, dt, M, N, K, splits, variant):
     dY = rnd((M, N), dev, dt, 1)
     X = rnd((M, K), dev, dt, 2)
     dW = torch.zeros(N, K, device=dev, dtype=torch.float32)
@@ -209,7 +209,7 @@ def test_gemm_tn(ops, dev, dt, M, N, K, splits):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_gemm_tn_conv_weight_grad(ops, dev, dt):
+def test_gemm_tn_conv_weight_grad(ops, dev, dt, variant):
     B, H, W, Ci, Co = 2, 12, 20, 64, 128
     x = rnd((B, Ci, H, W), dev, dt, 1)
     dy_ = rnd((B, Co, H, W), dev, dt, 2)
