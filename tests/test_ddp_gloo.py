@@ -1,0 +1,50 @@
+"""N > 1 path on CPU: two gloo ranks run the gradient reducer (the same code drives RCCL on the GPUs)."""
+import importlib
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ddp = importlib.import_module("small-object-detection-transformers_amd.ddp")
+    flat = torch.full((1000,), float(rank + 1))
+    ddp.GradReducer(average=False).reduce(flat)            # reference semantics: SUM (Train.py:439-440)
+    ok1 = bool(torch.all(flat == 3.0))
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    ddp.GradReducer(average=True).reduce(flat)
+    ok2 = bool(torch.allclose(flat, torch.arange(10, dtype=torch.float32) * 1.5))
+    start, per = ddp.shard_batch(16, rank, world)
+    ok3 = (start, per) == (rank * 8, 8)
+    # attach(): parameters are broadcast from rank 0
+    lin = torch.nn.Linear(4, 4)
+    with torch.no_grad():
+        lin.weight.fill_(float(rank))
+    lin._get_engine = lambda: None
+    ddp.attach(lin, average=True)
+    ok4 = bool(torch.all(lin.weight == 0.0)) and lin._pending_ddp.world == 2
+    q.put((rank, ok1 and ok2 and ok3 and ok4))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+    assert res == {0: True, 1: True}
