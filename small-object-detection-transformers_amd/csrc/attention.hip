@@ -337,12 +337,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
                                                           const T* __restrict__ d_out, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, T* __restrict__ dqkv,
                                                           float* __restrict__ dbias_t, float* __restrict__ dq_acc,
-                                                          const AttnGeo g, int nwin_total) {
+                                                          const AttnGeo g, int nwin_total, int fulldb) {
   using L = Lay<T, HD>;
   constexpr int E = L::E, KPL = L::KPL;
   constexpr int NT = NW * 64;
   constexpr int LTMAX = 225;
   constexpr int MK = TT<T>::MMA_K;
+  extern __shared__ __attribute__((aligned(16))) float dbfull[];   // [NW][(2ws-1)^2] when fulldb (multi-tile windows)
   // only row-major [token][d] tiles are staged; every "transposed" MFMA operand is read with fragT
   __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE], sK[NW * L::QTILE], sV[NW * L::QTILE],
       sDO[NW * L::QTILE];
@@ -367,6 +368,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
   constexpr int CPR = NW * L::DCH;
 
   for (int i = tid; i < NW * (LTMAX + 3); i += NT) (&sDB[0][0])[i] = 0.f;
+  if (fulldb)
+    for (int i = tid; i < NW * L2 * L2; i += NT) dbfull[i] = 0.f;
 
   unsigned char* myQ = sQ + w * L::QTILE; unsigned char* myK = sK + w * L::QTILE;
   unsigned char* myV = sV + w * L::QTILE; unsigned char* myDO = sDO + w * L::QTILE;
@@ -605,17 +608,20 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
             const int qiy = sGeoQ[qn][0], qix = sGeoQ[qn][1];
 #pragma unroll
             for (int ns = 0; ns < 4; ++ns) {
-              atomicAdd(&sDB[w][(qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1)], dbacc[ms][ns][r]);
+              if (fulldb) atomicAdd(&dbfull[w * L2 * L2 + (qiy - kiy[ns] + g.ws - 1) * L2 + (qix - kix[ns] + g.ws - 1)], dbacc[ms][ns][r]);
+              else atomicAdd(&sDB[w][(qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1)], dbacc[ms][ns][r]);
               dbacc[ms][ns][r] = 0.f;
             }
           }
-        __syncthreads();
-        for (int i = lane; i < LT; i += 64) {
-          const int a = i / L2, c = i - a * L2;
-          const int gy = a - (R - 1) + dyoff + g.ws - 1;
-          const float v = sDB[w][i];
-          if (gy >= 0 && gy < L2 && v != 0.f) atomicAdd(dbias_t + (long)head * L2 * L2 + gy * L2 + c, v);
-          sDB[w][i] = 0.f;
+        if (!fulldb) {
+          __syncthreads();
+          for (int i = lane; i < LT; i += 64) {
+            const int a = i / L2, c = i - a * L2;
+            const int gy = a - (R - 1) + dyoff + g.ws - 1;
+            const float v = sDB[w][i];
+            if (gy >= 0 && gy < L2 && v != 0.f) atomicAdd(dbias_t + (long)head * L2 * L2 + gy * L2 + c, v);
+            sDB[w][i] = 0.f;
+          }
         }
       }
     }
@@ -637,6 +643,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
       T* dst = dqkv + (long)sTokK[r] * C3 + (hg * NW) * HD + cc * KPL;
       *(uint4*)(dst + g.C) = *(const uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16);
       *(uint4*)(dst + 2 * g.C) = *(const uint4*)(sV + (h * 64 + r) * L::QROW + dc * 16);
+    }
+  }
+  if (!single && fulldb) {
+    __syncthreads();
+    for (int i = lane; i < L2 * L2; i += 64) {
+      const float v = dbfull[w * L2 * L2 + i];
+      if (v != 0.f) atomicAdd(dbias_t + (long)head * L2 * L2 + i, v);
     }
   }
   if (single) {
@@ -701,12 +714,29 @@ int launch_bwd(const void* qkv, const float* bias_t, const void* out, const void
   const int nitems = nwin * g.nqt;
   int gx = nitems < 1024 ? nitems : 1024;
   constexpr bool PFOK = (4 * Lay<T, HD>::DCH <= 16);
-  if (PFOK && g.nqt == 1)
+  if (PFOK && g.nqt == 1) {
     hipLaunchKernelGGL((attn_bwd_kernel<T, HD, NW, PFOK>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
-                       (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin);
-  else
-    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, NW, false>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
-                       (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin);
+                       (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin, 0);
+  } else {
+    // multi-tile windows: keep the whole (2ws-1)^2 bias-gradient table of each head in LDS when it fits
+    using L = Lay<T, HD>;
+    const int L2 = 2 * g.ws - 1;
+    const int static_lds = NW * (4 * L::QTILE + 2 * L::STILE) + 2 * NW * 228 * 4 + 2 * NW * 64 * 4 + 2048;
+    const int dyn = NW * L2 * L2 * 4;
+    int fulldb = (g.nqt > 1 && static_lds + dyn <= 160 * 1024) ? 1 : 0;
+    if (fulldb) {
+      static int attr_bytes = 0;
+      if (dyn > attr_bytes) {
+        if (hipFuncSetAttribute((const void*)attn_bwd_kernel<T, HD, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) {
+          (void)hipGetLastError();
+          fulldb = 0;
+        } else attr_bytes = dyn;
+      }
+      if (gx > 128) gx = 128;      // few, long-lived workgroups: one table flush each
+    }
+    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, NW, false>), dim3(gx, g.heads / NW), dim3(NW * 64), fulldb ? dyn : 0, st,
+                       (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin, fulldb);
+  }
   if (g.nqt > 1)
     hipLaunchKernelGGL((attn_dq_finish_kernel<T>), dim3(1024), dim3(256), 0, st, dq_acc, (T*)dqkv, M, g.C);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;

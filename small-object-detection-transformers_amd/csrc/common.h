@@ -82,7 +82,7 @@ template <> __device__ __forceinline__ uint4 pack<bf16>(const float* f) {
 // Gaussian exp(-x^2/2) it shares with gelu'(x): ~14 VALU ops instead of libm erff's ~50.
 __device__ __forceinline__ void erf_gauss(float x, float& erfv, float& gauss) {
   const float ax = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   gauss = __expf(-ax * ax);
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
@@ -100,7 +100,7 @@ __device__ __forceinline__ float dgelu_f(float x) {
   erf_gauss(x, e, g);
   return 0.5f * (1.0f + e) + x * 0.3989422804014327f * g;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // reductions inside a 16-lane group (lanes sharing l >> 4) and a full wave
 __device__ __forceinline__ float group16_max(float v) {

@@ -48,10 +48,13 @@ __device__ __forceinline__ sodt_seg pick_seg(const sodt_aspec& a, int i) {
 }
 
 // fused epilogue of one 16-byte output chunk: v[KPL] = accumulators of row m, columns n .. n+KPL-1
-template <typename T>
-__device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int flags, const long m, const int n,
+// CF >= 0: the epilogue flag set is a compile-time constant (the handful of combinations the model uses get
+// branch-free instantiations); CF < 0: flags are read at run time (generic fallback).
+template <typename T, int CF = -1>
+__device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int rtflags, const long m, const int n,
                                           float (&v)[TT<T>::KPL], const int hw) {
   constexpr int KPL = TT<T>::KPL;
+  const int flags = CF >= 0 ? CF : rtflags;
   const bool out32 = (flags & SODT_EPI_OUT_F32) != 0;
   const bool full = (n + KPL <= g.N);
   if (flags & SODT_EPI_BIAS) {
@@ -102,7 +105,7 @@ __device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int fla
     for (int j = 0; j < KPL; ++j) v[j] += x[j];
   }
   long orow = m;
-  if (g.oscatter) {
+  if (CF < 0 && g.oscatter) {
     const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
     const int y = rem / g.a.Wo, x = rem - y * g.a.Wo;
     orow = ((long)b * g.OH + y * g.omul + g.ody) * g.OW + x * g.omul + g.odx;
@@ -125,7 +128,7 @@ __device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int fla
   }
 }
 
-template <typename T>
+template <typename T, int CF>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g) {
   constexpr int KPL = TT<T>::KPL;
   constexpr int BK = 8 * KPL;                 // elements per K-step
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
         sC[(wr * 64 + i * 16 + fg * 4 + r) * EPI_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
   __syncthreads();
 
-  const int flags = g.flags;
+  const int flags = CF >= 0 ? CF : g.flags;
   if (flags & SODT_EPI_STATS) {
     if (tid < BN && n0 + tid < g.N) {
       double s = 0.0, s2 = 0.0;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
       const float4 t = *(const float4*)(sC + r * EPI_LD + c + j);
       v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
     }
-    epi_chunk<T>(g, flags, m, n, v, hw);
+    epi_chunk<T, CF>(g, flags, m, n, v, hw);
   }
 }
 
@@ -476,7 +479,8 @@ int launch_as(const sodt_gemm_args* g, hipStream_t st) {
 // and wave instruction, no LDS staging and one barrier pair per row block.  Workgroups that walk the
 // same row blocks (one per column tile) are placed on one XCD so that A is fetched from HBM once.
 // ---------------------------------------------------------------------------------
-template <typename T, int BN_, bool STATS>
+// CF: compile-time epilogue flags (or -1); SIMPLE: A is one plain row-major tensor (no segments / spatial map)
+template <typename T, int BN_, bool STATS, int CF, bool SIMPLE>
 __global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g, const int teams_per_xcd) {
   constexpr int KPL = TT<T>::KPL;
   constexpr int MK = TT<T>::MMA_K;
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g,
   const int wr = wid >> 1, wc = wid & 1;
   const int fr = lane & 15, fg = lane >> 4;
   const int hw = g.a.Ho * g.a.Wo;
-  const int flags = g.flags;
+  const int flags = CF >= 0 ? CF : g.flags;
   const int ntiles = (g.N + BN_ - 1) / BN_;
   // block -> (team, column tile): the ntiles members of a team share an XCD (blockIdx % 8) and walk the same row blocks
   const int xcd = blockIdx.x & 7, ix = blockIdx.x >> 3;
@@ -525,7 +529,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g,
       if (id < AS_BM * CPRK) {
         const int r = id / CPRK, c = id - r * CPRK;
         const long m = m0 + r;
-        if (m < g.M) {
+        if (SIMPLE) {
+          if (m < g.M) areg[i] = *(const uint4*)((const T*)g.a.s[0].p + m * g.a.s[0].ld + c * KPL);
+        } else if (m < g.M) {
           int kcol = c * KPL, si = 0;
           while (si + 1 < g.a.nseg && kcol >= sSeg[si].klen) { kcol -= sSeg[si].klen; ++si; }
           const sodt_seg sg = sSeg[si];
@@ -668,7 +674,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g,
 #pragma unroll
               for (int j = 0; j < KPL; ++j) v[j] += x[j];
             }
-            if (n + c * KPL < g.N) epi_chunk<T>(g, eflags, m, n + c * KPL, v, hw);
+            if (n + c * KPL < g.N)
+              epi_chunk<T, (CF >= 0 ? (CF & ~(SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_DGELU)) : -1)>(g, eflags, m, n + c * KPL, v, hw);
           }
         }
       }
@@ -689,13 +696,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g,
   }
 }
 
-template <typename T, int BN_, bool STATS>
+template <typename T, int BN_, bool STATS, int CF, bool SIMPLE>
 int launch_bs(const sodt_gemm_args* g, hipStream_t st) {
   const int KB = g->K * (int)sizeof(T);
   const int lds = (BN_ + AS_BM) * KB;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bs_kernel<T, BN_, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_bs_kernel<T, BN_, STATS, CF, SIMPLE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
       return SODT_EINVAL;
     attr_set = true;
   }
@@ -707,7 +714,7 @@ int launch_bs(const sodt_gemm_args* g, hipStream_t st) {
   const long max_teams = (nrb + 7) / 8;
   if (teams_per_xcd > max_teams) teams_per_xcd = (int)max_teams;
   const int blocks = teams_per_xcd * ntiles * 8;
-  hipLaunchKernelGGL((gemm_bs_kernel<T, BN_, STATS>), dim3(blocks), dim3(256), lds, st, *g, teams_per_xcd);
+  hipLaunchKernelGGL((gemm_bs_kernel<T, BN_, STATS, CF, SIMPLE>), dim3(blocks), dim3(256), lds, st, *g, teams_per_xcd);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
@@ -1085,6 +1092,23 @@ bool aspec_ok(const sodt_aspec& a, int K, int kpl) {
 
 }  // namespace
 
+// branch-free instantiations for the flag sets the model's plain-tensor GEMMs use; everything else is generic
+template <typename T>
+int dispatch_bs(const sodt_gemm_args* g, bool simple, hipStream_t st) {
+  if (simple) {
+    switch (g->flags) {
+      case 0: return launch_bs<T, 128, false, 0, true>(g, st);
+      case SODT_EPI_BIAS: return launch_bs<T, 128, false, SODT_EPI_BIAS, true>(g, st);
+      case SODT_EPI_RESID: return launch_bs<T, 128, false, SODT_EPI_RESID, true>(g, st);
+      case SODT_EPI_BIAS | SODT_EPI_RESID: return launch_bs<T, 128, false, SODT_EPI_BIAS | SODT_EPI_RESID, true>(g, st);
+      case SODT_EPI_BIAS | SODT_EPI_GELU_DUAL: return launch_bs<T, 128, false, SODT_EPI_BIAS | SODT_EPI_GELU_DUAL, true>(g, st);
+      case SODT_EPI_DGELU: return launch_bs<T, 128, false, SODT_EPI_DGELU, true>(g, st);
+      default: break;
+    }
+  }
+  return launch_bs<T, 128, false, -1, false>(g, st);
+}
+
 extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st) {
   if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0) return SODT_EINVAL;
   const int kpl = dtype == SODT_BF16 ? 8 : 4;
@@ -1113,8 +1137,9 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
       const bool bs_ok = (g->N % kplv) == 0 && (g->flags & SODT_EPI_OUT_F32) == 0 && g_variant != 2;
       if (bs_ok) {
         const bool stt = (g->flags & SODT_EPI_STATS) != 0;
-        if (dtype == SODT_BF16) return stt ? launch_bs<bf16, 128, true>(g, s_) : launch_bs<bf16, 128, false>(g, s_);
-        if (dtype == SODT_F32) return stt ? launch_bs<float, 128, true>(g, s_) : launch_bs<float, 128, false>(g, s_);
+        const bool simple = g->a.nseg == 1 && !g->a.spatial && !g->oscatter;
+        if (dtype == SODT_BF16) return stt ? launch_bs<bf16, 128, true, -1, false>(g, s_) : dispatch_bs<bf16>(g, simple, s_);
+        if (dtype == SODT_F32) return stt ? launch_bs<float, 128, true, -1, false>(g, s_) : dispatch_bs<float>(g, simple, s_);
         return SODT_EINVAL;
       }
       if (dtype == SODT_BF16) return KB <= 384 ? launch_as<bf16, 128>(g, s_) : launch_as<bf16, 64>(g, s_);
@@ -1125,11 +1150,20 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
   const long tiles = ((long)(g->M + BM - 1) / BM) * ((g->N + BN - 1) / BN);
   if (tiles > 0x7fffffffL) return SODT_EINVAL;
   dim3 grid((unsigned)tiles), block(256);
-  if (dtype == SODT_BF16) {
-    hipLaunchKernelGGL(gemm_nt_kernel<bf16>, grid, block, 0, (hipStream_t)st, *g);
-  } else if (dtype == SODT_F32) {
-    hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, (hipStream_t)st, *g);
-  } else return SODT_EINVAL;
+  const int cf = g->oscatter ? -1 : g->flags;
+#define NT_CASE(TY, F) case F: hipLaunchKernelGGL((gemm_nt_kernel<TY, F>), grid, block, 0, (hipStream_t)st, *g); break
+#define NT_SWITCH(TY)                                                                                   \
+  switch (cf) {                                                                                         \
+    NT_CASE(TY, 0); NT_CASE(TY, SODT_EPI_BIAS); NT_CASE(TY, SODT_EPI_RESID);                            \
+    NT_CASE(TY, (SODT_EPI_BIAS | SODT_EPI_RESID)); NT_CASE(TY, (SODT_EPI_BIAS | SODT_EPI_GELU_DUAL));   \
+    NT_CASE(TY, SODT_EPI_DGELU);                                                                        \
+    default: hipLaunchKernelGGL((gemm_nt_kernel<TY, -1>), grid, block, 0, (hipStream_t)st, *g); break;  \
+  }
+  if (dtype == SODT_BF16) { NT_SWITCH(bf16) }
+  else if (dtype == SODT_F32) { NT_SWITCH(float) }
+  else return SODT_EINVAL;
+#undef NT_SWITCH
+#undef NT_CASE
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
