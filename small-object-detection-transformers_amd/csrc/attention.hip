@@ -20,6 +20,7 @@
 // and flushed with a few global atomics.
 #include "common.h"
 #include "../../include/sodt_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -69,6 +70,17 @@ __device__ __forceinline__ uint4 frag(const unsigned char* tile, int rowbytes, i
   const int k = kb * TT<T>::MMA_K + TT<T>::KPL * (lane >> 4);
   if (k >= klimit) return make_uint4(0, 0, 0, 0);
   return *(const uint4*)(tile + (row0 + (lane & 15)) * rowbytes + k * TT<T>::SZ);
+}
+
+// Register-resident prefetch slots.  (Plain uint4 arrays indexed in unrolled loops were left in scratch by
+// hipcc -- loaded, spilled, reloaded -- which serialises the prefetch; named members + a compile-time loop
+// keep them in VGPRs.)
+struct U4x4 { uint4 a, b, c, d; };
+template <int I> __device__ __forceinline__ uint4& u4at(U4x4& r) {
+  if constexpr (I == 0) return r.a; else if constexpr (I == 1) return r.b; else if constexpr (I == 2) return r.c; else return r.d;
+}
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
 // MFMA operand fragment whose contraction index runs along the LDS ROWS of a [K rows][cols] tile
@@ -275,6 +287,198 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
   }
 }
 
+// issue the global loads of one 8x8 window's Q, K, V chunks of this thread into registers
+template <typename T, int HD, int NW, int NPF>
+__device__ __forceinline__ void attn_issue_qkv(const AttnGeo& g, const T* __restrict__ qkv, int item, int hg, int tid,
+                                               U4x4& aq, U4x4& ak, U4x4& av) {
+  using L = Lay<T, HD>;
+  constexpr int KPL = L::KPL, NT = NW * 64, CPR = NW * L::DCH;
+  const int C3 = 3 * g.C;
+  int t_ = item;
+  const int wx_ = t_ % g.nwx; t_ /= g.nwx;
+  const int wy_ = t_ % g.nwy; const int b_ = t_ / g.nwy;
+  static_for<0, NPF>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const int idx = tid + i * NT;
+    const int r = idx / CPR, cc = idx - r * CPR;
+    int row, rid, iy, ix;
+    win_token(g, b_, wy_, wx_, r, row, rid, iy, ix);
+    const T* src = qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL;
+    u4at<i>(aq) = *(const uint4*)(src);
+    u4at<i>(ak) = *(const uint4*)(src + g.C);
+    u4at<i>(av) = *(const uint4*)(src + 2 * g.C);
+  });
+}
+
+// ---------------------------------------------------------------------------------
+// forward, 8x8 windows (one 64-token tile per window: stages 1 and 2).  Persistent workgroups walk the
+// windows of one head group; the next window's Q/K/V chunks are prefetched into registers.  Scores are
+// computed TRANSPOSED (S^T = K Q^T: keys on accumulator rows, queries on lanes) so that a query's softmax
+// is 16 in-lane values + two cross-group shuffles, and P leaves the accumulators as packed 4-key stores
+// straight into the [q][key] layout the P V product reads.  Bias values (x log2 e) sit in 64 registers.
+// ---------------------------------------------------------------------------------
+template <typename T, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
+                                                               T* __restrict__ out, float* __restrict__ lse, const AttnGeo g,
+                                                               int nwin_total) {
+  using L = Lay<T, HD>;
+  constexpr int E = L::E, KPL = L::KPL, NT = NW * 64, CPR = NW * L::DCH, NPF = L::DCH, MK = TT<T>::MMA_K;
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE], sK[NW * L::QTILE], sV[NW * L::QTILE];
+  __shared__ __attribute__((aligned(16))) unsigned char sP[NW * L::STILE];
+  __shared__ float sL[NW][64];
+  __shared__ int sTok[64];
+  __shared__ short sRid[64];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int hg = blockIdx.y, head = hg * NW + w;
+  const int C3 = 3 * g.C, L2 = 2 * g.ws - 1;
+  const float scale2 = rsqrtf((float)HD) * SODT_LOG2E;
+  const float* bt = bias_t + (long)head * L2 * L2;
+  unsigned char* myQ = sQ + w * L::QTILE; unsigned char* myK = sK + w * L::QTILE;
+  unsigned char* myV = sV + w * L::QTILE; unsigned char* myP = sP + w * L::STILE;
+
+  // bias2[ks][ms][r]: key = ks*16 + 4*fg + r (accumulator row), query = ms*16 + fr (lane)
+  float bias2[4][4][4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kn = ks * 16 + fg * 4 + r;
+      const int kiy = kn / g.ws, kix = kn - kiy * g.ws;
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        const int qn = ms * 16 + fr;
+        const int qiy = qn / g.ws, qix = qn - qiy * g.ws;
+        bias2[ks][ms][r] = bt[(qiy - kiy + g.ws - 1) * L2 + (qix - kix + g.ws - 1)] * SODT_LOG2E;
+      }
+    }
+
+  // prefetch slots as individual registers (arrays / structs were left in scratch by hipcc, serialising the prefetch)
+  uint4 pq0, pq1, pq2, pq3, pk0, pk1, pk2, pk3, pv0, pv1, pv2, pv3;
+#define FWD_ISSUE_ONE(i, ITEM)                                                          \
+  if constexpr (NPF > i) {                                                              \
+    int t_ = (ITEM);                                                                    \
+    const int wx_ = t_ % g.nwx; t_ /= g.nwx;                                            \
+    const int wy_ = t_ % g.nwy; const int b_ = t_ / g.nwy;                              \
+    const int idx = tid + i * NT;                                                       \
+    const int r = idx / CPR, cc = idx - r * CPR;                                        \
+    int row, rid, iy, ix;                                                               \
+    win_token(g, b_, wy_, wx_, r, row, rid, iy, ix);                                    \
+    const T* src = qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL;                    \
+    pq##i = *(const uint4*)(src); pk##i = *(const uint4*)(src + g.C); pv##i = *(const uint4*)(src + 2 * g.C); \
+  }
+#define FWD_ISSUE(ITEM) { FWD_ISSUE_ONE(0, ITEM) FWD_ISSUE_ONE(1, ITEM) FWD_ISSUE_ONE(2, ITEM) FWD_ISSUE_ONE(3, ITEM) }
+#define FWD_STORE_ONE(i)                                                                \
+  if constexpr (NPF > i) {                                                              \
+    const int idx = tid + i * NT;                                                       \
+    const int r = idx / CPR, cc = idx - r * CPR;                                        \
+    const int h = cc / L::DCH, dc = cc - h * L::DCH;                                    \
+    const int off = (h * 64 + r) * L::QROW + dc * 16;                                   \
+    *(uint4*)(sQ + off) = pq##i; *(uint4*)(sK + off) = pk##i; *(uint4*)(sV + off) = pv##i; \
+  }
+  FWD_ISSUE((int)blockIdx.x < nwin_total ? (int)blockIdx.x : 0)
+
+  for (int item = blockIdx.x; item < nwin_total; item += gridDim.x) {
+    int t = item;
+    const int wx = t % g.nwx; t /= g.nwx;
+    const int wy = t % g.nwy; const int b = t / g.nwy;
+    const bool msk = g.shift > 0 && (wy == g.nwy - 1 || wx == g.nwx - 1);
+    __syncthreads();                                   // previous window fully consumed
+    if (tid < 64) {
+      int row, rid, iy, ix;
+      win_token(g, b, wy, wx, tid, row, rid, iy, ix);
+      sTok[tid] = row; sRid[tid] = (short)rid;
+    }
+    FWD_STORE_ONE(0) FWD_STORE_ONE(1) FWD_STORE_ONE(2) FWD_STORE_ONE(3)
+    __syncthreads();
+    FWD_ISSUE(item + (int)gridDim.x < nwin_total ? item + (int)gridDim.x : item)
+
+    // ---- S^T = K Q^T
+    f32x4 s[4][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) s[ks][ms] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < L::KBQ; ++kb) {
+      uint4 fk[4], fq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { fk[i] = frag<T>(myK, L::QROW, i * 16, kb, HD, lane); fq[i] = frag<T>(myQ, L::QROW, i * 16, kb, HD, lane); }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) mma16<T>(s[ks][ms], fk[ks], fq[ms]);
+    }
+    // ---- softmax over keys for query (ms, fr): 16 in-lane values, then across the four 16-lane groups
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      const int qrid = msk ? (int)sRid[ms * 16 + fr] : 0;
+      float mx = -1e30f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(s[ks][ms][r], scale2, bias2[ks][ms][r]);
+          if (msk && qrid != (int)sRid[ks * 16 + fg * 4 + r]) v += -100.0f * SODT_LOG2E;
+          s[ks][ms][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float p = fast_exp2(s[ks][ms][r] - mx); s[ks][ms][r] = p; sum += p; }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      if (fg == 0) {
+        const int qn = ms * 16 + fr;
+        sL[w][qn] = __builtin_amdgcn_rcpf(sum);
+        if (lse) lse[(long)sTok[qn] * g.heads + head] = mx * (1.0f / SODT_LOG2E) + __logf(sum);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st4<T>(myP + (ms * 16 + fr) * L::TROW + (ks * 16 + fg * 4) * E, s[ks][ms]);
+    }
+    __syncthreads();
+    // ---- O = P V
+    f32x4 o[4][HD / 16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int d = 0; d < HD / 16; ++d) o[i][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < L::KBT; ++kb) {
+      uint4 fb[HD / 16];
+#pragma unroll
+      for (int d = 0; d < HD / 16; ++d) fb[d] = fragT<T>(myV, L::QROW, kb * MK, d * 16, lane);
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        const uint4 fa = frag<T>(myP, L::TROW, ms * 16, kb, 64, lane);
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) mma16<T>(o[ms][d], fa, fb[d]);
+      }
+    }
+    // ---- normalise, stage through this head's Q tile, coalesced store
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qn = ms * 16 + fg * 4 + r;
+        const float inv = sL[w][qn];
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) st_elem<T>(myQ + qn * L::QROW + (d * 16 + fr) * E, o[ms][d][r] * inv);
+      }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CPR; idx += NT) {
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int h = cc / L::DCH, dc = cc - h * L::DCH;
+      *(uint4*)(out + (long)sTok[r] * g.C + (hg * NW) * HD + cc * KPL) = *(const uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------
@@ -308,25 +512,25 @@ __global__ __launch_bounds__(256) void attn_dq_finish_kernel(float* __restrict__
 template <typename T, int HD, int NW, int NPF>
 __device__ __forceinline__ void attn_prefetch(const AttnGeo& g, const T* __restrict__ qkv, const T* __restrict__ d_out,
                                               const float* __restrict__ lse, int item, int hg, int head, int tid, int lane,
-                                              uint4 (&pq)[NPF], uint4 (&pk)[NPF], uint4 (&pv)[NPF], uint4 (&pdo)[NPF], float& plse) {
+                                              U4x4& pq, U4x4& pk, U4x4& pv, U4x4& pdo, float& plse) {
   using L = Lay<T, HD>;
   constexpr int KPL = L::KPL, NT = NW * 64, CPR = NW * L::DCH;
   const int C3 = 3 * g.C;
   int t_ = item;
   const int wx_ = t_ % g.nwx; t_ /= g.nwx;
   const int wy_ = t_ % g.nwy; const int b_ = t_ / g.nwy;
-#pragma unroll
-  for (int i = 0; i < NPF; ++i) {
+  static_for<0, NPF>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
     const int idx = tid + i * NT;
     const int r = idx / CPR, cc = idx - r * CPR;
     int row, rid, iy, ix;
     win_token(g, b_, wy_, wx_, r, row, rid, iy, ix);
     const T* src = qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL;
-    pq[i] = *(const uint4*)(src);
-    pk[i] = *(const uint4*)(src + g.C);
-    pv[i] = *(const uint4*)(src + 2 * g.C);
-    pdo[i] = *(const uint4*)(d_out + (long)row * g.C + (hg * NW) * HD + cc * KPL);
-  }
+    u4at<i>(pq) = *(const uint4*)(src);
+    u4at<i>(pk) = *(const uint4*)(src + g.C);
+    u4at<i>(pv) = *(const uint4*)(src + 2 * g.C);
+    u4at<i>(pdo) = *(const uint4*)(d_out + (long)row * g.C + (hg * NW) * HD + cc * KPL);
+  });
   int row, rid, iy, ix;
   win_token(g, b_, wy_, wx_, lane, row, rid, iy, ix);
   plse = lse[(long)row * g.heads + head];
@@ -388,8 +592,38 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
   // registers while the current window is computed, so no global-memory latency is exposed inside the loop.
   constexpr bool pf = FAST;                       // FAST <=> one 64-token tile per window and 4*DCH <= 16 registers
   constexpr int NPF = FAST ? L::DCH : 1;          // chunks per thread and tensor (64*CPR / NT)
-  uint4 pq[NPF], pk[NPF], pv[NPF], pdo[NPF];
+  uint4 pq0, pq1, pq2, pq3, pk0, pk1, pk2, pk3, pv0, pv1, pv2, pv3, pd0, pd1, pd2, pd3;
   float plse = 0.f;
+#define BWD_ISSUE_ONE(i, ITEM)                                                          \
+  if constexpr (FAST && NPF > i) {                                                      \
+    int t_ = (ITEM);                                                                    \
+    const int wx_ = t_ % g.nwx; t_ /= g.nwx;                                            \
+    const int wy_ = t_ % g.nwy; const int b_ = t_ / g.nwy;                              \
+    const int idx = tid + i * NT;                                                       \
+    const int r = idx / CPR, cc = idx - r * CPR;                                        \
+    int row, rid, iy, ix;                                                               \
+    win_token(g, b_, wy_, wx_, r, row, rid, iy, ix);                                    \
+    const T* src = qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL;                    \
+    pq##i = *(const uint4*)(src); pk##i = *(const uint4*)(src + g.C); pv##i = *(const uint4*)(src + 2 * g.C); \
+    pd##i = *(const uint4*)(d_out + (long)row * g.C + (hg * NW) * HD + cc * KPL);       \
+  }
+#define BWD_ISSUE(ITEM) {                                                               \
+    BWD_ISSUE_ONE(0, ITEM) BWD_ISSUE_ONE(1, ITEM) BWD_ISSUE_ONE(2, ITEM) BWD_ISSUE_ONE(3, ITEM) \
+    int t2_ = (ITEM);                                                                   \
+    const int wx2_ = t2_ % g.nwx; t2_ /= g.nwx;                                         \
+    const int wy2_ = t2_ % g.nwy; const int b2_ = t2_ / g.nwy;                          \
+    int row2, rid2, iy2, ix2;                                                           \
+    win_token(g, b2_, wy2_, wx2_, lane, row2, rid2, iy2, ix2);                          \
+    plse = lse[(long)row2 * g.heads + head];                                            \
+  }
+#define BWD_STORE_ONE(i)                                                                \
+  if constexpr (FAST && NPF > i) {                                                      \
+    const int idx = tid + i * NT;                                                       \
+    const int r = idx / CPR, cc = idx - r * CPR;                                        \
+    const int h = cc / L::DCH, dc = cc - h * L::DCH;                                    \
+    const int off = (h * 64 + r) * L::QROW + dc * 16;                                   \
+    *(uint4*)(sQ + off) = pq##i; *(uint4*)(sK + off) = pk##i; *(uint4*)(sV + off) = pv##i; *(uint4*)(sDO + off) = pd##i; \
+  }
   // per-lane bias values (x log2 e) of its 64 (q, key) positions: identical for every window of this head
   float bias2[4][4][4];
 #pragma unroll
@@ -412,8 +646,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
           bias2[ms][ns][r] = bt[(qiy - kiy_ + g.ws - 1) * L2 + (qix - kix_ + g.ws - 1)] * SODT_LOG2E;
         }
       }
-    if ((int)blockIdx.x < nitems)
-      attn_prefetch<T, HD, NW, NPF>(g, qkv, d_out, lse, blockIdx.x, hg, head, tid, lane, pq, pk, pv, pdo, plse);
+    BWD_ISSUE((int)blockIdx.x < nitems ? (int)blockIdx.x : 0)
   }
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     int t = item;
@@ -428,20 +661,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
       sTokK[tid] = row; sGeoK[tid][0] = (short)iy; sGeoK[tid][1] = (short)ix; sGeoK[tid][2] = (short)rid;
     }
     if constexpr (pf) {
-#pragma unroll
-      for (int i = 0; i < NPF; ++i) {
-        const int idx = tid + i * NT;
-        const int r = idx / CPR, cc = idx - r * CPR;
-        const int h = cc / L::DCH, dc = cc - h * L::DCH;
-        const int off = (h * 64 + r) * L::QROW + dc * 16;
-        *(uint4*)(sQ + off) = pq[i]; *(uint4*)(sK + off) = pk[i]; *(uint4*)(sV + off) = pv[i]; *(uint4*)(sDO + off) = pdo[i];
-      }
+      BWD_STORE_ONE(0) BWD_STORE_ONE(1) BWD_STORE_ONE(2) BWD_STORE_ONE(3)
       sLse[w][lane] = plse * SODT_LOG2E;
     }
     __syncthreads();
     if constexpr (pf) {
-      if (item + (int)gridDim.x < nitems)
-        attn_prefetch<T, HD, NW, NPF>(g, qkv, d_out, lse, item + gridDim.x, hg, head, tid, lane, pq, pk, pv, pdo, plse);
+      {   // unconditional (clamped) so that the prefetch registers stay registers
+        const int nxt = item + (int)gridDim.x < nitems ? item + (int)gridDim.x : item;
+        BWD_ISSUE(nxt)
+      }
     } else {
       for (int idx = tid; idx < 64 * CPR; idx += NT) {
         const int r = idx / CPR, cc = idx - r * CPR;
@@ -693,6 +921,15 @@ bool make_geo(AttnGeo& g, int B, int H, int W, int C, int heads, int ws, int shi
 template <typename T, int HD, int NW>
 int launch_fwd(const void* qkv, const float* bias_t, void* out, float* lse, const AttnGeo& g, hipStream_t st) {
   if (g.heads % NW) return SODT_EINVAL;
+  if constexpr (3 * Lay<T, HD>::DCH <= 12) {
+    if (g.nqt == 1) {
+      const int nwin = g.B * g.nwy * g.nwx;
+      const int gx = nwin < 512 ? nwin : 512;
+      hipLaunchKernelGGL((attn_fwd_fast_kernel<T, HD, NW>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
+                         (const T*)qkv, bias_t, (T*)out, lse, g, nwin);
+      return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+    }
+  }
   const long blocks = (long)g.B * g.nwy * g.nwx * g.nqt * (g.heads / NW);
   hipLaunchKernelGGL((attn_fwd_kernel<T, HD, NW>), dim3((unsigned)blocks), dim3(NW * 64), 0, st,
                      (const T*)qkv, bias_t, (T*)out, lse, g);
