@@ -72,17 +72,6 @@ __device__ __forceinline__ uint4 frag(const unsigned char* tile, int rowbytes, i
   return *(const uint4*)(tile + (row0 + (lane & 15)) * rowbytes + k * TT<T>::SZ);
 }
 
-// Register-resident prefetch slots.  (Plain uint4 arrays indexed in unrolled loops were left in scratch by
-// hipcc -- loaded, spilled, reloaded -- which serialises the prefetch; named members + a compile-time loop
-// keep them in VGPRs.)
-struct U4x4 { uint4 a, b, c, d; };
-template <int I> __device__ __forceinline__ uint4& u4at(U4x4& r) {
-  if constexpr (I == 0) return r.a; else if constexpr (I == 1) return r.b; else if constexpr (I == 2) return r.c; else return r.d;
-}
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
 // MFMA operand fragment whose contraction index runs along the LDS ROWS of a [K rows][cols] tile
 // (lane reads column col0 + (l&15), rows k0 + KPL*(l>>4) .. +KPL-1): bf16 through the transposing
 // ds_read_b64_tr_b16 (two reads of 4 rows), f32 through four strided ds_read_b32.  EXEC must be full.
@@ -287,29 +276,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
   }
 }
 
-// issue the global loads of one 8x8 window's Q, K, V chunks of this thread into registers
-template <typename T, int HD, int NW, int NPF>
-__device__ __forceinline__ void attn_issue_qkv(const AttnGeo& g, const T* __restrict__ qkv, int item, int hg, int tid,
-                                               U4x4& aq, U4x4& ak, U4x4& av) {
-  using L = Lay<T, HD>;
-  constexpr int KPL = L::KPL, NT = NW * 64, CPR = NW * L::DCH;
-  const int C3 = 3 * g.C;
-  int t_ = item;
-  const int wx_ = t_ % g.nwx; t_ /= g.nwx;
-  const int wy_ = t_ % g.nwy; const int b_ = t_ / g.nwy;
-  static_for<0, NPF>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    const int idx = tid + i * NT;
-    const int r = idx / CPR, cc = idx - r * CPR;
-    int row, rid, iy, ix;
-    win_token(g, b_, wy_, wx_, r, row, rid, iy, ix);
-    const T* src = qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL;
-    u4at<i>(aq) = *(const uint4*)(src);
-    u4at<i>(ak) = *(const uint4*)(src + g.C);
-    u4at<i>(av) = *(const uint4*)(src + 2 * g.C);
-  });
-}
-
 // ---------------------------------------------------------------------------------
 // forward, 8x8 windows (one 64-token tile per window: stages 1 and 2).  Persistent workgroups walk the
 // windows of one head group; the next window's Q/K/V chunks are prefetched into registers.  Scores are
@@ -506,34 +472,6 @@ __global__ __launch_bounds__(256) void attn_dq_finish_kernel(float* __restrict__
     dqkv[tok * 3 * C + c] = from_f<T>(acc[i]);
     acc[i] = 0.f;   // the accumulator is left zeroed for the next call
   }
-}
-
-// issue the global loads of one 8x8 window (Q, K, V, dO chunks of this thread + its lane's lse) into registers
-template <typename T, int HD, int NW, int NPF>
-__device__ __forceinline__ void attn_prefetch(const AttnGeo& g, const T* __restrict__ qkv, const T* __restrict__ d_out,
-                                              const float* __restrict__ lse, int item, int hg, int head, int tid, int lane,
-                                              U4x4& pq, U4x4& pk, U4x4& pv, U4x4& pdo, float& plse) {
-  using L = Lay<T, HD>;
-  constexpr int KPL = L::KPL, NT = NW * 64, CPR = NW * L::DCH;
-  const int C3 = 3 * g.C;
-  int t_ = item;
-  const int wx_ = t_ % g.nwx; t_ /= g.nwx;
-  const int wy_ = t_ % g.nwy; const int b_ = t_ / g.nwy;
-  static_for<0, NPF>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    const int idx = tid + i * NT;
-    const int r = idx / CPR, cc = idx - r * CPR;
-    int row, rid, iy, ix;
-    win_token(g, b_, wy_, wx_, r, row, rid, iy, ix);
-    const T* src = qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL;
-    u4at<i>(pq) = *(const uint4*)(src);
-    u4at<i>(pk) = *(const uint4*)(src + g.C);
-    u4at<i>(pv) = *(const uint4*)(src + 2 * g.C);
-    u4at<i>(pdo) = *(const uint4*)(d_out + (long)row * g.C + (hg * NW) * HD + cc * KPL);
-  });
-  int row, rid, iy, ix;
-  win_token(g, b_, wy_, wx_, lane, row, rid, iy, ix);
-  plse = lse[(long)row * g.heads + head];
 }
 
 template <typename T, int HD, int NW, bool FAST>
@@ -991,7 +929,7 @@ extern "C" int sodt_window_attn_fwd(const void* qkv, const float* bias_t, void* 
   if (dtype == SODT_BF16) {
     if (hd == 16) return launch_fwd<bf16, 16, 4>(qkv, bias_t, out, lse, g, st);
     if (hd == 32) return launch_fwd<bf16, 32, 4>(qkv, bias_t, out, lse, g, st);
-    if (hd == 64) return launch_fwd<bf16, 64, 4>(qkv, bias_t, out, lse, g, st);
+    if (hd == 64) return launch_fwd<bf16, 64, 2>(qkv, bias_t, out, lse, g, st);
   } else if (dtype == SODT_F32) {
     if (hd == 16) return launch_fwd<float, 16, 4>(qkv, bias_t, out, lse, g, st);
     if (hd == 32) return launch_fwd<float, 32, 2>(qkv, bias_t, out, lse, g, st);
@@ -1011,7 +949,7 @@ extern "C" int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const 
   if (dtype == SODT_BF16) {
     if (hd == 16) return launch_bwd<bf16, 16, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
     if (hd == 32) return launch_bwd<bf16, 32, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
-    if (hd == 64) return launch_bwd<bf16, 64, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
+    if (hd == 64) return launch_bwd<bf16, 64, 1>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
   } else if (dtype == SODT_F32) {
     if (hd == 16) return launch_bwd<float, 16, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
     if (hd == 32) return launch_bwd<float, 32, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
