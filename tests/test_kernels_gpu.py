@@ -224,7 +224,7 @@ def test_gemm_tn_conv_weight_grad(ops, dev, dt, variant):
 
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("Cc", [192, 384, 768])
+@pytest.mark.parametrize("Cc", [64, 128, 192, 384, 768])
 def test_layernorm(ops, dev, dt, Cc):
     M = 777
     x = rnd((M, Cc), dev, dt, 1) * 2 + 0.5
