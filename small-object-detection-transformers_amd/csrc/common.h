@@ -102,14 +102,18 @@ __device__ __forceinline__ float dgelu_f(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// reductions inside a 16-lane group (lanes sharing l >> 4) and a full wave
+// reductions inside a 16-lane group (lanes sharing l >> 4): four DPP steps on the VALU (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror) instead of ds_bpermute shuffles through the LDS pipe; every lane ends with the result
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float group16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
-  v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+  v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
   return v;
 }
 __device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {

@@ -223,9 +223,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
   const int fr = lane & 15, fg = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_regs(kt + 1);
+    if (kt + 1 < nk && !(CF < 0 && (g.flags & (1 << 22)))) load_regs(kt + 1);
     const unsigned char* a_s = sA + buf * STAGE_BYTES;
     const unsigned char* b_s = sB + buf * STAGE_BYTES;
+    if (!(CF < 0 && (g.flags & (1 << 21))))
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       uint4 fa[4], fb[4];
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
       const float4 t = *(const float4*)(sC + r * EPI_LD + c + j);
       v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
     }
-    epi_chunk<T, CF>(g, flags, m, n, v, hw);
+    if (!(CF < 0 && (g.flags & (1 << 20)))) epi_chunk<T, CF>(g, flags, m, n, v, hw);
   }
 }
 
