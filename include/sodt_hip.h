@@ -137,6 +137,19 @@ int sodt_frontend_bwd(const float* rgb, const float* ir, long ir_bstride, const 
                       float* dw, float* db, float* dgamma, float* dbeta, int B, int S, int ca_ws,
                       int dtype, sodt_stream_t st);
 
+/* General cross-channel attention (window ca_ws in 1..8, optional cyclic shift; backbone_vit.py:469-561, :589-616) as
+ * separate stages: e = 4x Conv2d(1->48,k4,s4) embeddings, f32 [B*t*t][192] (caller's workspace); then per pair
+ * softmax((q k^T + mask)/2) v + residual + LayerNorm(48).  The backward accumulates d e with atomics (zero it first);
+ * dw/db/dgamma/dbeta accumulate.  ca_ws == 1 callers should use the fused sodt_frontend_* instead. */
+int sodt_patch_embed4_fwd(const float* rgb, const float* ir, long ir_bstride, const float* w, const float* b,
+                          float* e, int B, int S, sodt_stream_t st);
+int sodt_patch_embed4_bwd(const float* rgb, const float* ir, long ir_bstride, const float* de, float* dw, float* db,
+                          int B, int S, sodt_stream_t st);
+int sodt_cross_attn_ln_fwd(const float* e, const float* gamma, const float* beta, void* out, int B, int S, int ws,
+                           int shift, int dtype, sodt_stream_t st);
+int sodt_cross_attn_ln_bwd(const float* e, const float* gamma, const void* dout, float* de, float* dgamma,
+                           float* dbeta, int B, int S, int ws, int shift, int dtype, sodt_stream_t st);
+
 /* BatchNorm2d (eps 1e-3, momentum 0.03) + SiLU of the head's Conv (common.py:38-50,
  * torch_utils.py:150-152), token-major.  stats f64 [2][C] from SODT_EPI_STATS.
  * finalize: mean/rstd (f32 [2][C]) + running-stat update (unbiased var); stats == NULL

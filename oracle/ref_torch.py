@@ -249,10 +249,11 @@ def patch_merging(sd: SD, pfx: str, x: Tensor, H: int, W: int) -> Tensor:
     return layer_norm(x, sd[pfx + "norm.weight"], sd[pfx + "norm.bias"])
 
 
-def image_encoder(sd: SD, x4: Tensor, pfx: str = "image_encoder.", taps: Optional[dict] = None) -> List[Tensor]:
+def image_encoder(sd: SD, x4: Tensor, pfx: str = "image_encoder.", taps: Optional[dict] = None,
+                  ca_window: int = 1, ca_shift: int = 0) -> List[Tensor]:
     """ImageEncoderViT.forward (backbone_vit.py:190-272), resolution-parameterised:
     stage resolutions are t, t/2, t/4 with t = S/4."""
-    x = frontend(sd, x4, pfx)
+    x = frontend(sd, x4, pfx, ca_window, ca_shift)
     B, h, w, c = x.shape
     if taps is not None:
         taps["frontend"] = x
@@ -359,11 +360,11 @@ def head(sd: SD, feats: Sequence[Tensor], training: bool, new_stats: Optional[di
 
 
 def model_forward(sd: SD, x_rgb: Tensor, x_ir: Tensor, training: bool = True,
-                  new_stats: Optional[dict] = None, taps: Optional[dict] = None):
+                  new_stats: Optional[dict] = None, taps: Optional[dict] = None, ca_window: int = 1, ca_shift: int = 0):
     """Model.forward, input_mode='RGB+IR' (model.py:191-192, :207-211, :245-294).
     train -> ([raw], y) ; eval -> (z, [raw], y)."""
     x4 = torch.cat([x_rgb, x_ir[:, 0:1]], 1)
-    feats = image_encoder(sd, x4, taps=taps)
+    feats = image_encoder(sd, x4, taps=taps, ca_window=ca_window, ca_shift=ca_shift)
     raw, y = head(sd, feats, training, new_stats)
     if training:
         return [raw], y + [[raw]]

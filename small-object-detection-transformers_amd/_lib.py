@@ -69,6 +69,10 @@ SIGNATURES = {
     "sodt_window_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sodt_frontend_fwd": [_P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sodt_frontend_bwd": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sodt_patch_embed4_fwd": [_P, _P, _L, _P, _P, _P, _I, _I, _P],
+    "sodt_patch_embed4_bwd": [_P, _P, _L, _P, _P, _P, _I, _I, _P],
+    "sodt_cross_attn_ln_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sodt_cross_attn_ln_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sodt_bn_finalize": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
     "sodt_bn_affine": [_P, _P, _P, _P, _P, _I, _P],
     "sodt_bn_silu_fwd": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P],

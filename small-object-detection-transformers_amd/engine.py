@@ -262,7 +262,14 @@ class Engine:
         # (2) front end: live call (input pointers change per step)
         x0 = plan.buf("x0", (B * t * t, 192))
         fe = P["fe"]
-        ops.frontend_fwd(x_rgb, x_ir, x_ir.shape[1] * S * S, fe["w"], fe["b"], fe["g"], fe["be"], x0, B, S, 1)
+        cb = self.model.image_encoder.chan_block
+        ca_ws, ca_shift = int(cb.window_size), int(cb.shift_size)
+        if ca_ws == 1:      # the shipped configuration (backbone_vit.py:438): fused kernel
+            ops.frontend_fwd(x_rgb, x_ir, x_ir.shape[1] * S * S, fe["w"], fe["b"], fe["g"], fe["be"], x0, B, S, 1)
+        else:               # general window / shift form of CAttentionBlock
+            e = plan.buf("fe.e", (B * t * t, 192), torch.float32)
+            ops.patch_embed4_fwd(x_rgb, x_ir, x_ir.shape[1] * S * S, fe["w"], fe["b"], e, B, S)
+            ops.cross_attn_ln_fwd(e, fe["g"], fe["be"], x0, B, S, ca_ws, ca_shift)
         # (3) encoder + head (recorded)
         if plan.fwd_main is None:
             with ops.Recorder() as rec:
@@ -547,8 +554,16 @@ class Engine:
             ops.replay(plan.bwd_main, probes=self.probes_bwd)
         # (3) front end: live
         fe = P["fe"]
-        ops.frontend_bwd(x_rgb, x_ir, x_ir.shape[1] * S * S, fe["w"], fe["b"], fe["g"], fe["be"], plan.bufs["g.dx0"],
-                         self.g_fe_w, self.g_fe_b, self.g_fe_g, self.g_fe_be, B, S, 1)
+        cb = self.model.image_encoder.chan_block
+        ca_ws, ca_shift = int(cb.window_size), int(cb.shift_size)
+        if ca_ws == 1:
+            ops.frontend_bwd(x_rgb, x_ir, x_ir.shape[1] * S * S, fe["w"], fe["b"], fe["g"], fe["be"], plan.bufs["g.dx0"],
+                             self.g_fe_w, self.g_fe_b, self.g_fe_g, self.g_fe_be, B, S, 1)
+        else:
+            de = plan.buf("fe.de", (B * t * t, 192), torch.float32)
+            ops.zero_(de)
+            ops.cross_attn_ln_bwd(plan.bufs["fe.e"], fe["g"], plan.bufs["g.dx0"], de, self.g_fe_g, self.g_fe_be, B, S, ca_ws, ca_shift)
+            ops.patch_embed4_bwd(x_rgb, x_ir, x_ir.shape[1] * S * S, de, self.g_fe_w, self.g_fe_b, B, S)
         if self.ddp is not None:
             self.ddp.reduce(self.flat_grad)
 

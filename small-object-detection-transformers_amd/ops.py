@@ -226,6 +226,22 @@ def frontend_bwd(rgb, ir_plane, ir_bstride, w, b, gamma, beta, dout, dw, db, dga
             _p(dw), _p(db), _p(dgamma), _p(dbeta), B, S, ca_ws, dt_code(dout))
 
 
+def patch_embed4_fwd(rgb, ir_plane, ir_bstride, w, b, e, B, S):
+    _launch("sodt_patch_embed4_fwd", _p(rgb), _p(ir_plane), ir_bstride, _p(w), _p(b), _p(e), B, S)
+
+
+def patch_embed4_bwd(rgb, ir_plane, ir_bstride, de, dw, db, B, S):
+    _launch("sodt_patch_embed4_bwd", _p(rgb), _p(ir_plane), ir_bstride, _p(de), _p(dw), _p(db), B, S)
+
+
+def cross_attn_ln_fwd(e, gamma, beta, out, B, S, ws, shift):
+    _launch("sodt_cross_attn_ln_fwd", _p(e), _p(gamma), _p(beta), _p(out), B, S, ws, shift, dt_code(out))
+
+
+def cross_attn_ln_bwd(e, gamma, dout, de, dgamma, dbeta, B, S, ws, shift):
+    _launch("sodt_cross_attn_ln_bwd", _p(e), _p(gamma), _p(dout), _p(de), _p(dgamma), _p(dbeta), B, S, ws, shift, dt_code(dout))
+
+
 def bn_finalize(stats, mean_rstd, running_mean, running_var, count, Cc, eps, momentum):
     _launch("sodt_bn_finalize", _p(stats), _p(mean_rstd), _p(running_mean), _p(running_var), count, Cc,
             C.c_float(eps), C.c_float(momentum))

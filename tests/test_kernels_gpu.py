@@ -17,8 +17,8 @@ def tol(dt):
 
 
 def close(a, b, dt, scale=None, what=""):
-    a = a.double()
-    b = b.double()
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
     rt, at = tol(dt)
     s = float(b.abs().max()) if scale is None else scale
     err = float((a - b).abs().max())
@@ -327,6 +327,47 @@ def test_frontend(ops, dev, dt):
     ref.backward(dout.float().double())
     dw, db, dg, dbe = torch.zeros_like(w), torch.zeros_like(b), torch.zeros_like(g), torch.zeros_like(be)
     ops.frontend_bwd(x_rgb, ir_plane, 3 * S * S, w, b, g, be, dout, dw, db, dg, dbe, B, S)
+    for ci, c in enumerate("rgbi"):
+        close(dw[ci], sdd[f"image_encoder.channel_embed_{c}.proj.weight"].grad.view(48, 16), dt, what=f"dw {c}")
+        close(db[ci], sdd[f"image_encoder.channel_embed_{c}.proj.bias"].grad, dt, what=f"db {c}")
+        close(dg[ci], sdd[f"image_encoder.chan_block.norm{ci + 1}.weight"].grad, dt, what=f"dgamma {ci}")
+        close(dbe[ci], sdd[f"image_encoder.chan_block.norm{ci + 1}.bias"].grad, dt, what=f"dbeta {ci}")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("ws,shift", [(1, 0), (2, 0), (2, 1), (4, 2), (8, 3)])
+def test_cross_channel_attention_general(ops, dev, dt, ws, shift):
+    """window >= 1 / shifted form of CAttentionBlock (the reference ships window 1) against the oracle."""
+    from oracle import ref_torch as R
+    B, S = 2, 64
+    sd = {k: v.to(dev) for k, v in R.procedural_state_dict(S, 8).items() if "channel_embed" in k or "chan_block" in k}
+    x_rgb, x_ir = R.synthetic_inputs(B, S, seed=7)
+    x_rgb, x_ir = x_rgb.to(dev), x_ir.to(dev)
+    w = torch.stack([sd[f"image_encoder.channel_embed_{c}.proj.weight"].view(48, 16) for c in "rgbi"]).contiguous() * 3
+    b = torch.stack([sd[f"image_encoder.channel_embed_{c}.proj.bias"] for c in "rgbi"]).contiguous()
+    g = torch.stack([sd[f"image_encoder.chan_block.norm{i}.weight"] for i in range(1, 5)]).contiguous()
+    be = torch.stack([sd[f"image_encoder.chan_block.norm{i}.bias"] for i in range(1, 5)]).contiguous()
+    t = S // 4
+    M = B * t * t
+    e = torch.zeros(M, 192, device=dev)
+    out = torch.zeros(M, 192, device=dev, dtype=dt)
+    ops.patch_embed4_fwd(x_rgb, x_ir, 3 * S * S, w, b, e, B, S)
+    ops.cross_attn_ln_fwd(e, g, be, out, B, S, ws, shift)
+    sdd = {k: v.double().cpu() for k, v in sd.items()}      # oracle on the CPU (its mask helper builds CPU tensors)
+    for ci, c in enumerate("rgbi"):
+        sdd[f"image_encoder.channel_embed_{c}.proj.weight"] = (w[ci].double().cpu().view(48, 1, 4, 4))
+    sdd = {k: v.requires_grad_(True) for k, v in sdd.items()}
+    x4 = torch.cat([x_rgb, x_ir[:, 0:1]], 1).double().cpu()
+    planes = R.channel_embeds(sdd, x4)
+    close(e, torch.cat(planes, -1).reshape(M, 192), torch.float32, what="embeds")
+    ref = torch.cat(R.cattention_block(sdd, *planes, window_size=ws, shift=shift), -1).reshape(M, 192)
+    close(out, ref, dt, what="cross attn fwd")
+    dout = rnd((M, 192), dev, dt, 9)
+    ref.backward(dout.float().double().cpu())
+    de = torch.zeros(M, 192, device=dev)
+    dw, db, dg, dbe = torch.zeros_like(w), torch.zeros_like(b), torch.zeros_like(g), torch.zeros_like(be)
+    ops.cross_attn_ln_bwd(e, g, dout, de, dg, dbe, B, S, ws, shift)
+    ops.patch_embed4_bwd(x_rgb, x_ir, 3 * S * S, de, dw, db, B, S)
     for ci, c in enumerate("rgbi"):
         close(dw[ci], sdd[f"image_encoder.channel_embed_{c}.proj.weight"].grad.view(48, 16), dt, what=f"dw {c}")
         close(db[ci], sdd[f"image_encoder.channel_embed_{c}.proj.bias"].grad, dt, what=f"db {c}")

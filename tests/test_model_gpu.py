@@ -138,3 +138,25 @@ def test_replay_and_accumulation(dev):
     p3[0].square().mean().backward()
     for n, p in model.named_parameters():
         assert torch.allclose(p.grad, g1[n], rtol=2e-3, atol=1e-6), n
+
+
+def test_general_cross_channel_window(dev):
+    """CAttentionBlock with window 2 + shift 1 (the form the reference code expresses but never enables)."""
+    from oracle import ref_torch as R
+    S, B = 128, 1
+    model, sd = build(dev, S)
+    model.compute_dtype = torch.float32
+    model.image_encoder.chan_block.window_size = 2
+    model.image_encoder.chan_block.shift_size = 1
+    model.train()
+    x_rgb, x_ir = R.synthetic_inputs(B, S, seed=5)
+    pred, _ = model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
+    pred[0].square().mean().backward()
+    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "anchor" not in k) for k, v in sd.items()}
+    opred, _ = R.model_forward(osd, x_rgb, x_ir, True, {}, None, 2, 1)
+    opred[0].square().mean().backward()
+    e, s = rel(pred[0], opred[0])
+    assert e <= 1e-3, e
+    for n in ("image_encoder.channel_embed_g.proj.weight", "image_encoder.chan_block.norm3.weight", "image_encoder.channel_embed_i.proj.bias"):
+        g, og = dict(model.named_parameters())[n].grad.cpu(), osd[n].grad
+        assert float((g - og).norm() / og.norm()) < 5e-3, n
