@@ -16,6 +16,7 @@
  */
 #ifndef SODT_HIP_H
 #define SODT_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -182,6 +183,26 @@ int sodt_detect_unpermute(const float* dpred, void* dz, int ldz, int B, int HW, 
 /* Detect eval decode (model.py:61-64): raw f32 (B,na,ny,nx,no) -> z f32 (B, na*ny*nx, no) */
 int sodt_detect_decode(const float* raw, const float* anchor_grid, float* z, int B, int na, int ny, int nx,
                        int no, float stride, sodt_stream_t st);
+
+/* ---- non_max_suppression (general.py:425-512), one image per call, eval only ---------------------------
+ * z: decoded rows (N, 5+nc) f32 [cx cy w h obj cls...] of one image (Detect eval output, model.py:64).
+ * sodt_nms_candidates: general.py:433,446-476 - rows with obj > conf; multi_label (forced off when nc == 1):
+ *   one candidate per class with obj*cls > conf, else the best class; class_allow (nc bytes, device, nullable)
+ *   is the `classes` filter (general.py:479-480).  Writes *count (device int, may exceed cap - then the call must
+ *   be repeated with a larger cap) and one 64-bit key per candidate, (~score_bits << 32) | (row*nc + class).
+ * sodt_nms_select: sorts the keys (descending score, ties in the reference's candidate order), keeps the top
+ *   30000 (general.py:489-490), runs class-offset NMS at iou_thres (torchvision.ops.nms semantics,
+ *   general.py:493-496), cuts at 300 (general.py:497-498), merge-NMS + redundancy filter when
+ *   1 < n_total < 3000 (general.py:499-506).  out: (<=300, 6) f32 [x1 y1 x2 y2 conf cls]; out_index: the
+ *   candidate id row*nc + class of each output row; *out_count: rows written.  ws: scratch of at least
+ *   sodt_nms_workspace_bytes(n_total).  Nothing synchronises; the caller reads *count / *out_count. */
+int sodt_nms_candidates(const float* z, int N, int nc, float conf_thres, int multi_label,
+                        const unsigned char* class_allow, unsigned long long* keys, int cap, int* count,
+                        sodt_stream_t st);
+int sodt_nms_workspace_bytes(long n_total, size_t* bytes);
+int sodt_nms_select(const float* z, int nc, const unsigned long long* keys, long n_total, float iou_thres,
+                    int agnostic, void* ws, size_t ws_bytes, float* out, int* out_index, int* out_count,
+                    sodt_stream_t st);
 
 /* Batched parameter preparation: out = cast(permute3(in)) for a device-resident table. */
 typedef struct {

@@ -245,13 +245,45 @@ def full_model_goldens(ref_model, out):
     print("[pin] wrote full_model_512.pt")
 
 
+def nms_goldens(out):
+    """Run the reference's own non_max_suppression (general.py:425) - with torchvision.ops.nms, absent from
+    this image, bound to the published greedy algorithm (R.greedy_nms) - and pin the oracle's restatement."""
+    sys.modules["torchvision.ops"].nms = R.greedy_nms
+    sys.modules["torchvision"].ops.nms = R.greedy_nms
+    G = importlib.import_module("reference.basics.utils.general")
+    cases = []
+    for (B, N, nc, conf, iou, ml, agn, classes, seed) in [
+            (2, 1200, 8, 0.25, 0.45, True, False, None, 1),      # n < 3000: merge-NMS + redundancy filter
+            (1, 6000, 8, 0.001, 0.6, True, False, None, 2),      # test.py:145 settings, n > 30000: truncation
+            (2, 1500, 8, 0.25, 0.45, False, False, None, 3),     # best-class path
+            (1, 1500, 8, 0.25, 0.45, True, True, [1, 5], 4),     # agnostic + class filter
+            (1, 64, 1, 0.25, 0.45, True, False, None, 5),        # nc == 1 (multi_label forced off)
+            (1, 50, 8, 0.999, 0.45, True, False, None, 6)]:      # nothing passes
+        z = R.synthetic_predictions(B, N, nc, seed=seed)
+        ref = G.non_max_suppression(z.clone(), conf, iou, classes=classes, agnostic=agn, multi_label=ml)
+        mine, idx = R.non_max_suppression(z.clone(), conf, iou, classes=classes, agnostic=agn, multi_label=ml, return_index=True)
+        for a, b in zip(ref, mine):
+            assert a.shape == b.shape, (a.shape, b.shape)
+            if a.numel():
+                assert maxdiff(a, b) < 1e-3, maxdiff(a, b)
+        print(f"[pin] NMS B={B} N={N} nc={nc} conf={conf} multi_label={ml}: kept {[int(a.shape[0]) for a in ref]} identical")
+        cases.append(dict(B=B, N=N, nc=nc, conf=conf, iou=iou, multi_label=ml, agnostic=agn, classes=classes, seed=seed,
+                          out=[a.clone() for a in ref], index=[i.clone() for i in idx]))
+    torch.save(cases, os.path.join(out, "nms.pt"))
+    print("[pin] wrote nms.pt")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only-nms", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
     ref_model, ref_vit, ref_common = import_reference()
+    nms_goldens(GOLD)
+    if a.only_nms:
+        return
     per_module_goldens(ref_vit, ref_common, GOLD)
     if not a.skip_full:
         full_model_goldens(ref_model, GOLD)

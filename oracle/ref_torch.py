@@ -408,6 +408,96 @@ def greedy_nms(boxes: Tensor, scores: Tensor, thr: float) -> Tensor:
     return order[torch.tensor(keep, dtype=torch.long)]
 
 
+def xywh2xyxy(x: Tensor) -> Tensor:
+    """general.py:270-277."""
+    y = x.clone()
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y
+
+
+def box_iou(box1: Tensor, box2: Tensor) -> Tensor:
+    """general.py:392-414."""
+    def area(b):
+        return (b[2] - b[0]) * (b[3] - b[1])
+    a1, a2 = area(box1.T), area(box2.T)
+    inter = (torch.min(box1[:, None, 2:], box2[:, 2:]) - torch.max(box1[:, None, :2], box2[:, :2])).clamp(0).prod(2)
+    return inter / (a1[:, None] + a2 - inter)
+
+
+def non_max_suppression(prediction: Tensor, conf_thres: float = 0.25, iou_thres: float = 0.45, classes=None,
+                        agnostic: bool = False, multi_label: bool = False, nms_fn=None, return_index: bool = False):
+    """general.py:425-512 (labels=() - no autolabelling), with torchvision.ops.nms restated
+    as greedy_nms (stable descending score order).  The over-max_nms truncation uses a stable
+    descending sort where the reference's argsort leaves tie order unspecified.
+    return_index: also return, per image, the candidate id  row * nc + class  (row = index into the
+    image's prediction rows) of every detection kept."""
+    nms_fn = nms_fn or greedy_nms
+    nc = prediction.shape[2] - 5
+    xc = prediction[..., 4] > conf_thres
+    max_wh, max_det, max_nms = 4096, 300, 30000
+    multi_label = multi_label and nc > 1
+    output = [torch.zeros((0, 6))] * prediction.shape[0]
+    index = [torch.zeros((0,), dtype=torch.long)] * prediction.shape[0]
+    for xi, x in enumerate(prediction):
+        rows = xc[xi].nonzero().view(-1)
+        x = x[xc[xi]].clone()
+        if not x.shape[0]:
+            continue
+        x[:, 5:] *= x[:, 4:5]
+        box = xywh2xyxy(x[:, :4])
+        if multi_label:
+            i, j = (x[:, 5:] > conf_thres).nonzero(as_tuple=False).T
+            x = torch.cat((box[i], x[i, j + 5, None], j[:, None].float()), 1)
+            ids = rows[i] * nc + j
+        else:
+            conf, j = x[:, 5:].max(1, keepdim=True)
+            sel = conf.view(-1) > conf_thres
+            x = torch.cat((box, conf, j.float()), 1)[sel]
+            ids = (rows * nc + j.view(-1))[sel]
+        if classes is not None:
+            sel = (x[:, 5:6] == torch.tensor(classes)).any(1)
+            x, ids = x[sel], ids[sel]
+        n = x.shape[0]
+        if not n:
+            continue
+        if n > max_nms:
+            o = torch.argsort(x[:, 4], descending=True, stable=True)[:max_nms]
+            x, ids = x[o], ids[o]
+        c = x[:, 5:6] * (0 if agnostic else max_wh)
+        boxes, scores = x[:, :4] + c, x[:, 4]
+        i = nms_fn(boxes, scores, iou_thres)
+        if i.shape[0] > max_det:
+            i = i[:max_det]
+        if 1 < n < 3E3:
+            iou = box_iou(boxes[i], boxes) > iou_thres
+            weights = iou * scores[None]
+            x[i, :4] = torch.mm(weights, x[:, :4]).float() / weights.sum(1, keepdim=True)
+            i = i[iou.sum(1) > 1]
+        output[xi] = x[i]
+        index[xi] = ids[i]
+    return (output, index) if return_index else output
+
+
+def synthetic_predictions(B: int, N: int, nc: int, seed: int = 0, img: float = 1024.0, clusters: int = 40) -> Tensor:
+    """Decoded-head-shaped (B, N, 5+nc) test rows: boxes scattered around `clusters` centres so
+    that many overlap above the IoU threshold; objectness / class scores spread over (0, 1)."""
+    g = torch.Generator().manual_seed(seed)
+    ctr = torch.rand(B, clusters, 2, generator=g) * img
+    size = 8 + torch.rand(B, clusters, 2, generator=g) * 56
+    which = torch.randint(0, clusters, (B, N), generator=g)
+    bi = torch.arange(B)[:, None]
+    xy = ctr[bi, which] + torch.randn(B, N, 2, generator=g) * 3.0
+    wh = size[bi, which] * (0.8 + 0.4 * torch.rand(B, N, 2, generator=g))
+    obj = torch.rand(B, N, 1, generator=g) ** 2
+    cls = torch.rand(B, N, nc, generator=g) ** 3
+    fav = torch.randint(0, nc, (B, clusters), generator=g)
+    cls.scatter_(2, fav[bi, which][..., None], 0.5 + 0.5 * torch.rand(B, N, 1, generator=g))
+    return torch.cat([xy, wh, obj, cls], 2).contiguous()
+
+
 # ----------------------------------------------------------------------------
 # parameter construction with the reference's names/shapes (SURVEY.md section 8b)
 # ----------------------------------------------------------------------------

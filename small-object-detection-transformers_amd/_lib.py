@@ -61,6 +61,9 @@ class PrepDesc(C.Structure):
 # name -> argtypes (all return int except sodt_version)
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
+    "sodt_nms_candidates": [_P, _I, _I, C.c_float, _I, _P, _P, _I, _P, _P],
+    "sodt_nms_workspace_bytes": [_L, C.POINTER(C.c_size_t)],
+    "sodt_nms_select": [_P, _I, _P, _L, C.c_float, _I, _P, C.c_size_t, _P, _P, _P, _P],
     "sodt_gemm_nt": [C.POINTER(GemmArgs), _I, _P],
     "sodt_gemm_tn": [C.POINTER(GemmTnArgs), _I, _P],
     "sodt_layernorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],

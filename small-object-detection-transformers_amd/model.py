@@ -298,6 +298,17 @@ def parse_model(d: dict, string: str, ch: List[int]):
     return nn.Sequential(*layers), sorted(save)
 
 
+class NMS(nn.Module):
+    """common.py:285-295: non_max_suppression as a module (thresholds are class attributes, as in the reference)."""
+    conf = 0.25
+    iou = 0.45
+    classes = None
+
+    def forward(self, x):
+        from .nms import non_max_suppression          # HIP path (csrc/nms.hip); raises on CPU tensors
+        return non_max_suppression(x[0], conf_thres=self.conf, iou_thres=self.iou, classes=self.classes)
+
+
 class Model(nn.Module):
     """basics/models/model.py:73-348 -- same constructor, forward signature, return tuples and attributes."""
     export = False
@@ -340,6 +351,7 @@ class Model(nn.Module):
         self.compute_dtype: Optional[torch.dtype] = None        # None: bf16 under autocast, else f32
         self.materialize_features = False
         self._engine = None
+        self._nms: Optional[NMS] = None      # set by .nms(); kept outside self.model so state_dict keys do not move
 
     # ------------------------------------------------------------------ reference helpers
     def _initialize_biases(self, cf=None):      # model.py:299-307
@@ -362,6 +374,14 @@ class Model(nn.Module):
                 m.conv = fused
                 delattr(m, "bn")
         self._engine = None
+        return self
+
+    def nms(self, mode=True):                    # model.py:327-339: add or remove the NMS stage (eval only)
+        if mode and self._nms is None:
+            self._nms = NMS()
+            self.eval()
+        elif not mode:
+            self._nms = None
         return self
 
     def info(self, verbose=False, img_size=640):
@@ -411,4 +431,8 @@ class Model(nn.Module):
         if training:
             return [pred], feats + [[pred]]
         z = eng.decode(pred)
+        if getattr(self, "_nms", None) is not None:
+            # the reference's `return y[0], y[1], features` (model.py:211) indexes the NMS list and fails for B == 1;
+            # here the detections take the place of z and the raw head output stays second
+            return self._nms((z, [pred])), [pred], feats + [(z, [pred])]
         return z, [pred], feats + [(z, [pred])]

@@ -282,6 +282,27 @@ def detect_decode(raw, anchor_grid, z, B, na, ny, nx, no, stride):
     _launch("sodt_detect_decode", _p(raw), _p(anchor_grid), _p(z), B, na, ny, nx, no, C.c_float(stride))
 
 
+def nms_candidates(z_img, conf_thres, multi_label, class_allow, keys, count):
+    """z_img (N, 5+nc) f32 of one image -> sort keys + device count (general.py:433-480)."""
+    N, no = z_img.shape
+    _launch("sodt_nms_candidates", _p(z_img), N, no - 5, C.c_float(conf_thres), int(bool(multi_label)),
+            _p(class_allow) if class_allow is not None else None, _p(keys), keys.numel(), _p(count))
+
+
+def nms_workspace_bytes(n_total: int) -> int:
+    b = C.c_size_t(0)
+    rc = _lib.sodt_nms_workspace_bytes(int(n_total), C.byref(b))
+    if rc != 0:
+        raise RuntimeError(f"sodt_nms_workspace_bytes failed with status {rc}")
+    return int(b.value)
+
+
+def nms_select(z_img, keys, n_total, iou_thres, agnostic, ws, out, out_index, out_count):
+    """Sort + NMS + max_det + merge-NMS of general.py:485-508 for one image."""
+    _launch("sodt_nms_select", _p(z_img), z_img.shape[1] - 5, _p(keys), int(n_total), C.c_float(iou_thres),
+            int(bool(agnostic)), _p(ws), ws.numel() * ws.element_size(), _p(out), _p(out_index), _p(out_count))
+
+
 def prep_weights(table_dev, n, max_elems, dtype_code):
     _launch("sodt_prep_weights", _p(table_dev), n, max_elems, dtype_code)
 

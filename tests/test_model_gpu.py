@@ -160,3 +160,29 @@ def test_general_cross_channel_window(dev):
     for n in ("image_encoder.channel_embed_g.proj.weight", "image_encoder.chan_block.norm3.weight", "image_encoder.channel_embed_i.proj.bias"):
         g, og = dict(model.named_parameters())[n].grad.cpu(), osd[n].grad
         assert float((g - og).norm() / og.norm()) < 5e-3, n
+
+
+def test_eval_with_nms_stage(dev):
+    """Model.nms() (model.py:327-339): eval forward -> decode -> non_max_suppression, all on the GPU; the detections
+    equal the oracle's NMS of the same decoded rows (identical candidate ids)."""
+    from oracle import ref_torch as R
+    model, _ = build(dev, 128)
+    model.compute_dtype = torch.float32
+    model.eval()
+    x_rgb, x_ir = R.synthetic_inputs(2, 128, seed=5)
+    with torch.no_grad():
+        z, praw, _ = model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
+        model.nms()
+        model._nms.conf = float(z[..., 4].median())        # random-init objectness is ~3e-4: keep about half the rows
+        dets, praw2, _ = model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
+    ref = R.non_max_suppression(z.cpu(), model._nms.conf, model._nms.iou)
+    assert len(dets) == 2
+    for d, r in zip(dets, ref):
+        assert d.shape == r.shape
+        if r.numel():
+            assert torch.equal(d[:, 4:].cpu(), r[:, 4:])
+            assert float((d[:, :4].cpu() - r[:, :4]).abs().max()) < 1e-3
+    model.nms(False)
+    with torch.no_grad():
+        z2, _, _ = model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
+    assert torch.equal(z, z2)

@@ -111,3 +111,18 @@ def test_greedy_nms_spec():
     assert keep.tolist() == [3, 2]          # 0,1 suppressed by 3 (IoU > 0.5); 4 suppressed by 2
     keep = R.greedy_nms(boxes, scores, 0.99)
     assert keep.tolist() == [3, 0, 1, 2, 4]
+
+
+def test_nms_oracle_matches_reference_golden():
+    """oracle non_max_suppression vs the outputs of the reference's own function (general.py:425), nms.pt."""
+    cases = torch.load(os.path.join(GOLD, "nms.pt"))
+    assert len(cases) >= 6
+    for c in cases:
+        z = R.synthetic_predictions(c["B"], c["N"], c["nc"], seed=c["seed"])
+        out, idx = R.non_max_suppression(z, c["conf"], c["iou"], classes=c["classes"], agnostic=c["agnostic"],
+                                         multi_label=c["multi_label"], return_index=True)
+        for o, i, ro, ri in zip(out, idx, c["out"], c["index"]):
+            assert o.shape == ro.shape
+            assert torch.equal(i, ri)
+            if o.numel():
+                assert float((o - ro).abs().max()) < 1e-3
