@@ -115,6 +115,68 @@ def _nhwc(x):   # (B,C,H,W) -> token-major (B*H*W, C)
     return x.permute(0, 2, 3, 1).reshape(B * H * W, Cc).contiguous()
 
 
+def test_gemm_nt_pipelined_bf16(ops, dev):
+    """The LDS-DMA pipelined bf16 kernel (csrc/gemm3.hip: N % 192 == 0, K >= 384): every epilogue it is built
+    for, a row tail, more tiles than workgroups (persistent walk), multi-segment and conv-tap A operands."""
+    dt = torch.bfloat16
+    ops.gemm_set_variant(0)
+    for (M, N, K) in [(256 * 130 + 100, 384, 768), (1000, 192, 384), (4096, 1152, 1536)]:
+        A = rnd((M, K), dev, dt, 1)
+        W = rnd((N, K), dev, dt, 2, 1 / math.sqrt(K))
+        bias = rnd((N,), dev, torch.float32, 3)
+        R = rnd((M, N), dev, dt, 4)
+        aux = rnd((M, N), dev, dt, 5)
+        base = A.float() @ W.float().t()
+        out = torch.zeros(M, N, device=dev, dtype=dt)
+        act = torch.zeros(M, N, device=dev, dtype=dt)
+        ops.gemm_nt([ops.SegSpec(A)], W, out, M, N, K)
+        close(out, base, dt, what=f"nt3 plain {M}x{N}x{K}")
+        ops.gemm_nt([ops.SegSpec(A)], W, out, M, N, K, bias=bias)
+        close(out, base + bias, dt, what="nt3 bias")
+        ops.gemm_nt([ops.SegSpec(A)], W, out, M, N, K, resid=R)
+        close(out, base + R.float(), dt, what="nt3 resid")
+        ops.gemm_nt([ops.SegSpec(A)], W, out, M, N, K, bias=bias, resid=R)
+        close(out, base + bias + R.float(), dt, what="nt3 bias+resid")
+        ops.gemm_nt([ops.SegSpec(A)], W, out, M, N, K, bias=bias, gelu_out=act)
+        close(out, base + bias, dt, what="nt3 pre")
+        close(act, F.gelu(base + bias), dt, what="nt3 gelu")
+        ops.gemm_nt([ops.SegSpec(A)], W, out, M, N, K, dgelu_aux=aux)
+        x = aux.float().double().requires_grad_(True)
+        F.gelu(x).sum().backward()
+        close(out, base.double() * x.grad, dt, what="nt3 dgelu")
+    # two concatenated K-segments with different leading dimensions
+    M, N = 2000, 192
+    A1f = rnd((M, 320), dev, dt, 6)             # 256 of 320 columns: leading dimension != segment length
+    A1 = A1f[:, :256]
+    A2 = rnd((M, 128), dev, dt, 7)
+    W = rnd((N, 384), dev, dt, 8, 0.05)
+    out = torch.zeros(M, N, device=dev, dtype=dt)
+    ops.gemm_nt([ops.SegSpec(A1f, 256, 0), ops.SegSpec(A2)], W, out, M, N, 384)
+    close(out, torch.cat([A1.float(), A2.float()], 1) @ W.float().t(), dt, what="nt3 concat")
+    # 2x2 conv (right/bottom zero pad) and its input gradient, C = 192 (the stage-1 conv MLP shapes)
+    B, H, Wd, Ci, Co = 2, 24, 40, 192, 192
+    x = rnd((B, Ci, H, Wd), dev, dt, 9)
+    xt = _nhwc(x)
+    M = B * H * Wd
+    w2 = rnd((Co, Ci, 2, 2), dev, dt, 10, 0.05)
+    bias = rnd((Co,), dev, torch.float32, 11)
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w2.float(), bias)
+    wg = w2.permute(0, 2, 3, 1).reshape(Co, 4 * Ci).contiguous()
+    segs = [ops.SegSpec(xt, Ci, 0, dy, dx, 1, 0, H, Wd) for dy in (0, 1) for dx in (0, 1)]
+    out = torch.zeros(M, Co, device=dev, dtype=dt)
+    ops.gemm_nt(segs, wg, out, M, Co, 4 * Ci, spatial=(H, Wd), bias=bias)
+    close(out, _nhwc(ref), dt, what="nt3 conv2x2")
+    dy_ = rnd((B, Co, H, Wd), dev, dt, 12)
+    xr = x.float().clone().requires_grad_(True)
+    F.conv2d(F.pad(xr, (0, 1, 0, 1)), w2.float(), bias).backward(dy_.float())
+    wgt = w2.permute(1, 2, 3, 0).reshape(Ci, 4 * Co).contiguous()
+    dyt = _nhwc(dy_)
+    segs = [ops.SegSpec(dyt, Co, 0, -dy, -dx, 1, 0, H, Wd) for dy in (0, 1) for dx in (0, 1)]
+    dx_ = torch.zeros(M, Ci, device=dev, dtype=dt)
+    ops.gemm_nt(segs, wgt, dx_, M, Ci, 4 * Co, spatial=(H, Wd))
+    close(dx_, _nhwc(xr.grad), dt, what="nt3 conv2x2 dx")
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gemm_nt_conv_taps(ops, dev, dt, variant):
     """2x2 conv with right/bottom zero pad (Mlp conv variant), 3x3 same conv, and their input gradients."""
