@@ -288,6 +288,301 @@ int launch_nt3(const sodt_gemm_args* g, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
+
+// ---------------------------------------------------------------------------------
+// Pipelined bf16 TN GEMM (weight gradients):  dW[N][K] += dY[M][N]^T @ X[M][K]  (+ dbias = column sums of dY).
+// Same machinery as the NT kernel above: LDS-DMA ring (5 stages of 32 rows, 4 in flight), one raw barrier per
+// stage, counted vmcnt, inline-asm fragment reads.  Both operands are contracted along their LDS ROWS, so the
+// fragments come from ds_read_b64_tr_b16 on row-major [m][col] images, XOR-swizzled on the 32-byte unit.
+// One workgroup owns a 256 x 192 tile of dW for one M-slice; the 256-wide side is whichever of N / K pads less
+// (SWAP: K on the 256 side), so the C = 192-multiple layer widths tile with little or no waste.  dbias is an
+// extra MFMA against a vector of ones (no LDS column walk).  Partial tiles are combined with f32 atomics.
+// ---------------------------------------------------------------------------------
+constexpr int N5_ROWS = 32, N5_NST = 5;
+constexpr int N5_PST = N5_ROWS * 512;               // P image: 256 bf16 per row
+constexpr int N5_QST = N5_ROWS * 384;               // Q image: 192 bf16 per row
+constexpr int N5_STAGE = N5_PST + N5_QST;           // 28 KiB
+constexpr int N5_SEGOFF = N5_NST * N5_STAGE;
+constexpr int N5_LDS = N5_SEGOFF + 48 * SODT_MAX_SEG;
+
+template <int OFF> __device__ __forceinline__ uint2 lds_rd_tr(uint32_t addr) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  u32x2 t;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t) : "v"(addr), "n"(OFF));
+  uint2 v; v.x = t.x; v.y = t.y;
+  return v;
+}
+template <int HI> __device__ __forceinline__ u32x4 tn3_frag(uint32_t addr) {
+  const uint2 lo = lds_rd_tr<0>(addr), hi = lds_rd_tr<HI>(addr);
+  u32x4 r; r.x = lo.x; r.y = lo.y; r.z = hi.x; r.w = hi.y;
+  return r;
+}
+
+struct XDesc { Seg3 sg; int off; int b, y, x; bool colok; const unsigned char* cur; };   // one X-side DMA instruction
+
+template <bool SWAP, bool SPATIAL>
+__global__ __launch_bounds__(512) void gemm_tn3_kernel(const sodt_gemm_tn_args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t lbase = lds_addr(dsm);
+  if (tid == 0) {
+#pragma unroll
+    for (int j = 0; j < SODT_MAX_SEG; ++j) {
+      unsigned char* e = dsm + N5_SEGOFF + 48 * j;
+      *(uint64_t*)(e) = (uint64_t)(uintptr_t)g.x.s[j].p;
+      *(int4*)(e + 16) = make_int4(g.x.s[j].ld, g.x.s[j].klen, g.x.s[j].dy, g.x.s[j].dx);
+      *(int4*)(e + 32) = make_int4(g.x.s[j].mul, g.x.s[j].shr, g.x.s[j].Hi, g.x.s[j].Wi);
+    }
+  }
+  __syncthreads();
+  const uint32_t segtab = lbase + N5_SEGOFF;
+
+  const int Pdim = SWAP ? g.K : g.N, Qdim = SWAP ? g.N : g.K;
+  const int ntp = (Pdim + 255) / 256, ntq = (Qdim + 191) / 192;
+  const int ntiles = ntp * ntq;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lid / ntiles, tile = lid - split * ntiles;
+  const int tq = tile % ntq, tp = tile / ntq;
+  const int P0 = tp * 256, Q0 = tq * 192;
+  const long rows_per = (((g.M + g.splits - 1) / g.splits) + N5_ROWS - 1) / N5_ROWS * N5_ROWS;
+  const long mbeg = (long)split * rows_per;
+  const long mend = (mbeg + rows_per < g.M) ? (mbeg + rows_per) : g.M;
+  if (mbeg >= mend) return;
+  const int nrows = (int)(mend - mbeg);
+  const int nsteps = (nrows + N5_ROWS - 1) / N5_ROWS;
+  const unsigned char* zero = (const unsigned char*)&g_zero16;
+  const int hw = g.x.Ho * g.x.Wo;
+
+  // ---- DMA descriptors.  P image: instruction j = 2 wid + e covers rows 2j, 2j+1 (32 chunks each);
+  //      Q image: linear chunk id = 64 j + lane -> row id / 24, chunk id % 24; waves 0-3 issue two, waves 4-7 one.
+  int prow[2], pcol[2], qrow[2], qcol[2];
+  const int nq = wid < 4 ? 2 : 1;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = 2 * (2 * wid + e) + (lane >> 5), c = lane & 31;
+    const int sw = (row & 3) | (((row >> 3) & 1) << 2);
+    prow[e] = row; pcol[e] = P0 + (((((c >> 1) ^ sw) << 1) | (c & 1)) << 3);
+    const int j = wid < 4 ? 2 * wid + e : 8 + (wid - 4);
+    const int id = 64 * j + lane;
+    const int r2 = id / 24, c2 = id - r2 * 24;
+    const int sw2 = ((r2 >> 1) & 1) | (((r2 >> 3) & 1) << 1);
+    qrow[e] = r2; qcol[e] = Q0 + (((((c2 >> 1) ^ sw2) << 1) | (c2 & 1)) << 3);
+  }
+  // dY-side instructions: a running pointer per instruction, advanced by 32 rows per stage.  Everything is kept in
+  // named scalars: arrays indexed through the lambdas end up in scratch, whose reloads drain the DMA queue.
+  const int ycol0 = SWAP ? qcol[0] : pcol[0], ycol1 = SWAP ? qcol[1] : pcol[1];
+  const int yrow0 = SWAP ? qrow[0] : prow[0], yrow1 = SWAP ? qrow[1] : prow[1];
+  const bool yok0 = ycol0 < g.N, yok1 = ycol1 < g.N;
+  const unsigned char* ycur0 = (const unsigned char*)g.dY + (((mbeg + yrow0) * g.ldy + (yok0 ? ycol0 : 0)) << 1);
+  const unsigned char* ycur1 = (const unsigned char*)g.dY + (((mbeg + yrow1) * g.ldy + (yok1 ? ycol1 : 0)) << 1);
+  const long ystep = (long)N5_ROWS * g.ldy * 2;
+  // X-side instructions: segment + offset of the fixed column; running pointer (plain) or row geometry (spatial)
+  const int xrow0 = SWAP ? prow[0] : qrow[0], xrow1 = SWAP ? prow[1] : qrow[1];
+  auto x_setup = [&](XDesc& d, int col, int xrow) {
+    d.colok = col < g.K;
+    int si = 0;
+    if (d.colok) {
+      for (int j = 0; j + 1 < g.x.nseg; ++j) {
+        const Seg3 t = load_seg3(segtab, si);
+        if (col >= t.klen) { col -= t.klen; ++si; }
+      }
+    }
+    d.sg = load_seg3(segtab, d.colok ? si : 0);
+    d.off = d.colok ? col : 0;
+    const long m = mbeg + xrow;
+    d.b = 0; d.y = 0; d.x = 0;
+    if (SPATIAL) {
+      const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+      d.b = b; d.y = rem / g.x.Wo; d.x = rem - d.y * g.x.Wo;
+    }
+    d.cur = d.sg.p + ((m * d.sg.ld + d.off) << 1);
+  };
+  XDesc xd0, xd1;
+  x_setup(xd0, SWAP ? pcol[0] : qcol[0], xrow0);
+  x_setup(xd1, SWAP ? pcol[1] : qcol[1], xrow1);
+  const long xstep0 = (long)N5_ROWS * xd0.sg.ld * 2, xstep1 = (long)N5_ROWS * xd1.sg.ld * 2;
+  int rel = 0;         // row base of the next stage to issue, relative to mbeg
+  auto x_src = [&](const XDesc& d, int xrow) -> const unsigned char* {
+    const unsigned char* r = zero;
+    if (d.colok && rel + xrow < nrows) {
+      if (SPATIAL) {
+        const Seg3& sg = d.sg;
+        const int yy = d.y * sg.mul + sg.dy, xx = d.x * sg.mul + sg.dx;
+        const int yi = yy >> sg.shr, xi = xx >> sg.shr;
+        if (yy >= 0 && xx >= 0 && yi < sg.Hi && xi < sg.Wi) {
+          const int sr = (d.b * sg.Hi + yi) * sg.Wi + xi;          // < 2^31 source rows
+          r = sg.p + (((long)sr * sg.ld + d.off) << 1);
+        }
+      } else {
+        r = d.cur;
+      }
+    }
+    return r;
+  };
+  auto x_adv = [&](XDesc& d, long step) {
+    if (SPATIAL) {          // advance the row by 32 tokens
+      d.x += N5_ROWS;
+      while (d.x >= g.x.Wo) { d.x -= g.x.Wo; ++d.y; }
+      if (d.y >= g.x.Ho) { d.y -= g.x.Ho; ++d.b; }
+    } else {
+      d.cur += step;
+    }
+  };
+  auto issue = [&](int slot) {
+    const uint32_t pdst = slot * N5_STAGE + wid * 2048;
+    const uint32_t qdst = slot * N5_STAGE + N5_PST + (wid < 4 ? wid * 2048 : 8192 + (wid - 4) * 1024);
+    const unsigned char* sy0 = (yok0 && rel + yrow0 < nrows) ? ycur0 : zero;
+    const unsigned char* sy1 = (yok1 && rel + yrow1 < nrows) ? ycur1 : zero;
+    const unsigned char* sx0 = x_src(xd0, xrow0);
+    const unsigned char* sx1 = x_src(xd1, xrow1);
+    __builtin_amdgcn_global_load_lds((glb_void*)(SWAP ? sx0 : sy0), (lds_void*)(dsm + pdst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void*)(SWAP ? sx1 : sy1), (lds_void*)(dsm + pdst + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void*)(SWAP ? sy0 : sx0), (lds_void*)(dsm + qdst), 16, 0, 0);
+    if (nq == 2) __builtin_amdgcn_global_load_lds((glb_void*)(SWAP ? sy1 : sx1), (lds_void*)(dsm + qdst + 1024), 16, 0, 0);
+    rel += N5_ROWS;
+    ycur0 += ystep; ycur1 += ystep;
+    x_adv(xd0, xstep0); x_adv(xd1, xstep1);
+  };
+
+  // ---- fragment read addresses: lane (fg, q = fr >> 2, p = fr & 3) reads 8 bytes of LDS row 8 fg + q (+4)
+  const int q_ = fr >> 2, p_ = fr & 3;
+  const int frow = 8 * fg + q_;
+  const int swP = q_ | ((fg & 1) << 2);
+  const int swQ = (q_ >> 1) | ((fg & 1) << 1);
+  uint32_t pa[4], qa[6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pa[i] = lbase + frow * 512 + (((wr * 4 + i) ^ swP) << 5) + 8 * p_;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) qa[j] = lbase + N5_PST + frow * 384 + (((wc * 6 + j) ^ swQ) << 5) + 8 * p_;
+
+  const bool wave_live = (P0 + wr * 64 < Pdim) && (Q0 + wc * 96 < Qdim);
+  // dbias: sums over m of the dY operand; done once per dY column by the tiles / waves on the first X tile
+  const bool do_bias = g.dbias != nullptr && (SWAP ? (tp == 0 && wr == 0) : (tq == 0 && wc == 0)) && wave_live;
+  u32x4 ones; ones.x = ones.y = ones.z = ones.w = 0x3F803F80u;
+
+  f32x4 acc[4][6], bacc[6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 6; ++j) bacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0); issue(1); issue(2); issue(3);
+  int slot = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    if (wid < 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(slot == 0 ? N5_NST - 1 : slot - 1);          // stage s + 4 -> slot (s + 4) % 5
+    if (wave_live) {
+      const uint32_t so = slot * N5_STAGE;
+      u32x4 fp[4], fq[6];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fp[i] = tn3_frag<2048>(pa[i] + so);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) fq[j] = tn3_frag<1536>(qa[j] + so);
+      T3_LGKM0();
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) mma_sw(acc[i][j], fp[i], fq[j]);
+      if (do_bias) {
+        if (SWAP) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) mma_sw(bacc[j], ones, fq[j]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mma_sw(bacc[i], fp[i], ones);
+        }
+      }
+    }
+    slot = slot == N5_NST - 1 ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();        // every wave is done with the stage images (the SWAP epilogue reuses them)
+  if (!wave_live) return;
+
+  // acc[i][j][r]: P column P0 + wr*64 + 16 i + 4 fg + r, Q column Q0 + wc*96 + 16 j + fr
+  if (!SWAP) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int qc = Q0 + wc * 96 + 16 * j + fr;
+        if (qc >= Qdim) continue;
+        int k = qc;
+        if (g.kperm_t > 1) k = (k % g.kperm_c) * g.kperm_t + k / g.kperm_c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = P0 + wr * 64 + 16 * i + 4 * fg + r;
+          if (n < Pdim) atomicAdd(g.dW + (long)n * g.lddw + k, acc[i][j][r]);
+        }
+      }
+  } else {
+    // K runs along the accumulator ROWS here: transpose each 16(k) x 96(n) strip through this wave's private LDS
+    // patch so that the 16 lanes of a group add to consecutive k of one dW row (coalesced atomics)
+    float* patch = (float*)(dsm + wid * (96 * 17 * 4));        // [n 96][k 16 (+1 pad)] f32 per wave, 6.4 KiB
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) patch[(16 * j + fr) * 17 + 4 * fg + r] = acc[i][j][r];
+      __builtin_amdgcn_wave_barrier();
+      const int pc = P0 + wr * 64 + 16 * i + fr;               // this lane's k
+      int k = pc;
+      if (g.kperm_t > 1) k = (k % g.kperm_c) * g.kperm_t + k / g.kperm_c;
+      for (int nn = fg; nn < 96; nn += 4) {
+        const int n = Q0 + wc * 96 + nn;
+        const float v = patch[nn * 17 + fr];
+        if (pc < Pdim && n < Qdim) atomicAdd(g.dW + (long)n * g.lddw + k, v);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (do_bias) {
+    if (SWAP) {          // bacc[j][*] rows all equal: column fr <-> n
+      if (fg == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int n = Q0 + wc * 96 + 16 * j + fr;
+          if (n < g.N) atomicAdd(g.dbias + n, bacc[j][0]);
+        }
+      }
+    } else {             // bacc[i][r]: row 4 fg + r <-> n, all columns equal
+      if (fr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = P0 + wr * 64 + 16 * i + 4 * fg + r;
+            if (n < g.N) atomicAdd(g.dbias + n, bacc[i][r]);
+          }
+      }
+    }
+  }
+}
+
+template <bool SWAP, bool SPATIAL>
+int launch_tn3(const sodt_gemm_tn_args* g, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_tn3_kernel<SWAP, SPATIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, N5_LDS) != hipSuccess) {
+      (void)hipGetLastError();
+      return SODT_EINVAL;
+    }
+    attr_set = true;
+  }
+  const int Pdim = SWAP ? g->K : g->N, Qdim = SWAP ? g->N : g->K;
+  const long tiles = (long)((Pdim + 255) / 256) * ((Qdim + 191) / 192);
+  hipLaunchKernelGGL((gemm_tn3_kernel<SWAP, SPATIAL>), dim3((unsigned)(tiles * g->splits)), dim3(512), N5_LDS, st, *g);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
 }  // namespace
 
 // eligibility of the pipelined kernel (bf16 only); the caller has validated pointers / alignment
@@ -317,4 +612,17 @@ int sodt_nt3_launch(const sodt_gemm_args* g, hipStream_t st) {
     case SODT_EPI_DGELU: return launch_nt3<SODT_EPI_DGELU>(g, st);
     default: return SODT_EINVAL;
   }
+}
+
+// pipelined TN: K on the 256-wide side when that pads less (ties keep N there); mirrored by ops.tn_splits
+bool sodt_tn3_swap(int N, int K) {
+  const long a = (long)((N + 255) / 256) * 256 * ((K + 191) / 192) * 192;
+  const long b = (long)((K + 255) / 256) * 256 * ((N + 191) / 192) * 192;
+  return b < a;
+}
+
+int sodt_tn3_launch(const sodt_gemm_tn_args* g, hipStream_t st) {
+  const bool sw = sodt_tn3_swap(g->N, g->K);
+  if (g->x.spatial) return sw ? launch_tn3<true, true>(g, st) : launch_tn3<false, true>(g, st);
+  return sw ? launch_tn3<true, false>(g, st) : launch_tn3<false, false>(g, st);
 }

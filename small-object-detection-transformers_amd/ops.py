@@ -168,9 +168,16 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
     _launch("sodt_gemm_nt", C.byref(g), dt_code(W))
 
 
-def tn_splits(M: int, N: int, K: int) -> int:
+def tn_splits(M: int, N: int, K: int, bf16: bool = False) -> int:
     """M-slices per dW tile so that the grid is one full round of workgroups (no tail): 256 x 192 tiles at one
-    workgroup per CU when the short side is <= 192, 128 x 128 tiles at two per CU otherwise (csrc/gemm.hip)."""
+    workgroup per CU when the short side is <= 192, 128 x 128 tiles at two per CU otherwise (csrc/gemm.hip).
+    bf16 (M >= 1024): the pipelined kernel of csrc/gemm3.hip - 256 x 192 tiles, the 256 side on whichever of
+    N / K pads less, one workgroup per CU, at least 16 stages of 32 rows per workgroup."""
+    if bf16 and M >= 1024 and N % 8 == 0 and K % 8 == 0 and not (N < 192 and K > 768):
+        a = ((N + 255) // 256) * ((K + 191) // 192)
+        b = ((K + 255) // 256) * ((N + 191) // 192)
+        tiles = b if b * 256 * 192 < a * 256 * 192 else a
+        return max(1, min(M // 512, max(1, 256 // tiles)))
     if N <= 192 or K <= 192:
         tiles, slots = ((N + 255) // 256) * ((K + 191) // 192), 256
     else:
@@ -194,7 +201,7 @@ def gemm_tn(dY: torch.Tensor, segs: Sequence[SegSpec], dW: torch.Tensor, M: int,
     g.M, g.N, g.K = M, N, K
     if kperm is not None:
         g.kperm_c, g.kperm_t = kperm
-    g.splits = tn_splits(M, N, K) if splits is None else splits
+    g.splits = tn_splits(M, N, K, dY.dtype == torch.bfloat16) if splits is None else splits
     _launch("sodt_gemm_tn", C.byref(g), dt_code(dY))
 
 

@@ -116,5 +116,7 @@ def test_parse_model_rejects_out_of_scope_modules(M):
 def test_host_helpers(ops):
     assert ops.tn_splits(524288, 768, 192) == 85 and ops.tn_splits(100, 768, 192) == 1
     assert ops.tn_splits(32768, 3072, 768) == 10
+    assert ops.tn_splits(524288, 192, 768, True) == 85 and ops.tn_splits(131072, 384, 384, True) == 64
+    assert ops.tn_splits(512, 192, 768, True) == ops.tn_splits(512, 192, 768)      # short M keeps the f32-path rule
     s = ops.SegSpec(torch.zeros(4, 96), 32, 64)
     assert (s.ld, s.klen, s.coff) == (96, 32, 64)

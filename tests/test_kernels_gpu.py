@@ -284,6 +284,52 @@ def test_gemm_tn_conv_weight_grad(ops, dev, dt, variant):
     close(dW, w2.grad, dt, what="conv2x2 dW (torch layout)")
 
 
+def test_gemm_tn_pipelined_bf16(ops, dev):
+    """The LDS-DMA pipelined bf16 weight-gradient kernel (csrc/gemm3.hip): both tile orientations, N / K tails,
+    ragged M slices, dbias through the ones-MFMA, conv taps with the torch-layout K permutation."""
+    dt = torch.bfloat16
+    ops.gemm_set_variant(0)
+    for (M, N, K, splits) in [(4096, 192, 768, None), (5000, 384, 384, 7), (2048 + 17, 576, 192, 3), (3000, 768, 192, None),
+                              (4096, 1152, 384, 5), (2000, 136, 200, 2), (8192, 1536, 384, None), (1024, 64, 64, 1)]:
+        dY = rnd((M, N), dev, dt, 1)
+        X = rnd((M, K), dev, dt, 2)
+        dW = torch.ones(N, K, device=dev, dtype=torch.float32)
+        db = torch.ones(N, device=dev, dtype=torch.float32)
+        ops.gemm_tn(dY, [ops.SegSpec(X)], dW, M, N, K, dbias=db, splits=splits)
+        ref = dY.float().double().t() @ X.float().double()
+        close(dW - 1, ref, dt, what=f"tn3 dW {M}x{N}x{K}")
+        close(db - 1, dY.float().double().sum(0), dt, what=f"tn3 dbias {M}x{N}x{K}")
+    # 2x2 conv weight gradient, C = 192 (stage-1 conv MLP), torch (Co, Ci, 2, 2) layout via kperm
+    B, H, Wd, Ci, Co = 2, 24, 40, 192, 192
+    x = rnd((B, Ci, H, Wd), dev, dt, 3)
+    dy_ = rnd((B, Co, H, Wd), dev, dt, 4)
+    w2 = (rnd((Co, Ci, 2, 2), dev, dt, 5, 0.05)).float().requires_grad_(True)
+    F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w2).backward(dy_.float())
+    xt, dyt = _nhwc(x), _nhwc(dy_)
+    segs = [ops.SegSpec(xt, Ci, 0, dy, dx, 1, 0, H, Wd) for dy in (0, 1) for dx in (0, 1)]
+    dW = torch.zeros(Co, Ci, 2, 2, device=dev, dtype=torch.float32)
+    ops.gemm_tn(dyt, segs, dW, B * H * Wd, Co, 4 * Ci, spatial=(H, Wd), kperm=(Ci, 4))
+    close(dW, w2.grad, dt, what="tn3 conv2x2 dW")
+    # 3x3 conv (head) with a two-tensor concat input
+    Ci1, Ci2, Co = 64, 128, 128
+    x1 = rnd((B, Ci1, H, Wd), dev, dt, 6)
+    x2 = rnd((B, Ci2, H, Wd), dev, dt, 7)
+    dy_ = rnd((B, Co, H, Wd), dev, dt, 8)
+    w3 = (rnd((Co, Ci1 + Ci2, 3, 3), dev, dt, 9, 0.05)).float().requires_grad_(True)
+    F.conv2d(torch.cat([x1, x2], 1).float(), w3, padding=1).backward(dy_.float())
+    x1t, x2t, dyt = _nhwc(x1), _nhwc(x2), _nhwc(dy_)
+    segs = []
+    for dy in range(3):
+        for dx in range(3):
+            segs.append(ops.SegSpec(x1t, Ci1, 0, dy - 1, dx - 1, 1, 0, H, Wd))
+    Cin = Ci1
+    dW = torch.zeros(Co, Cin, 3, 3, device=dev, dtype=torch.float32)
+    ops.gemm_tn(dyt, segs, dW, B * H * Wd, Co, 9 * Cin, spatial=(H, Wd), kperm=(Cin, 9))
+    w3b = (w3.detach()[:, :Ci1]).clone().requires_grad_(True)
+    F.conv2d(x1.float(), w3b, padding=1).backward(dy_.float())
+    close(dW, w3b.grad, dt, what="tn3 conv3x3 dW")
+
+
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("Cc", [64, 128, 192, 384, 768])
