@@ -1038,6 +1038,7 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
   if ((g->flags & SODT_EPI_STATS) && !g->stats) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_AFFINE_SILU) && (!g->scale || !g->shift || ((((uintptr_t)g->scale) | ((uintptr_t)g->shift)) & 15))) return SODT_EINVAL;
   if (g->oscatter && !g->a.spatial) return SODT_EINVAL;
+  if (dtype == SODT_BF16 && (g_variant == 0 || g_variant == 3) && sodt_nt3_eligible(g)) return sodt_nt3_launch(g, (hipStream_t)st);
   // short contraction -> A-stationary kernel (row bytes a multiple of 128 so the XOR swizzle stays in-row)
   {
     const int es = dtype == SODT_BF16 ? 2 : 4;
@@ -1060,7 +1061,7 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
       return SODT_EINVAL;
     }
   }
-  if (dtype == SODT_BF16 && g_variant == 0 && sodt_nt3_eligible(g)) return sodt_nt3_launch(g, (hipStream_t)st);
+  if (dtype == SODT_BF16 && (g_variant == 0 || g_variant == 3) && sodt_nt3_eligible(g)) return sodt_nt3_launch(g, (hipStream_t)st);
   const long tiles = ((long)(g->M + BM - 1) / BM) * ((g->N + BN - 1) / BN);
   if (tiles > 0x7fffffffL) return SODT_EINVAL;
   dim3 grid((unsigned)tiles), block(256);

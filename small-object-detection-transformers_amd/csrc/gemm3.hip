@@ -30,7 +30,9 @@ constexpr int T3_AST = T3_BM * 128;                 // 32 KiB per A stage
 constexpr int T3_BST = T3_BN * 128;                 // 24 KiB per W stage
 constexpr int T3_BOFF = 3 * T3_AST;                 // W ring after the A ring
 constexpr int T3_SEGOFF = T3_BOFF + 2 * T3_BST;     // segment table (48 B per entry)
-constexpr int T3_LDS = T3_SEGOFF + 48 * SODT_MAX_SEG;
+constexpr int T3_BIASOFF = T3_SEGOFF + 448;         // f32 bias[N], N <= 3072 (read with inline-asm LDS loads in the epilogue:
+constexpr int T3_MAXBIAS = 3072;                    //  an ordinary global load there would drain the DMA queue every tile)
+constexpr int T3_LDS = T3_BIASOFF + T3_MAXBIAS * 4;
 
 __device__ uint4 g_zero16;                          // DMA source of rows outside the image / beyond M
 
@@ -98,6 +100,8 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
       *(int4*)(e + 32) = make_int4(g.a.s[j].mul, g.a.s[j].shr, g.a.s[j].Hi, g.a.s[j].Wi);
     }
   }
+  if (CF & SODT_EPI_BIAS)
+    for (int i = tid; i < g.N; i += 512) *(float*)(dsm + T3_BIASOFF + 4 * i) = g.bias[i];
   __syncthreads();
   const uint32_t segtab = lbase + T3_SEGOFF;
 
@@ -262,7 +266,14 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
           float v[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) { v[r] = acc[u][t][0][r]; v[4 + r] = acc[u][t][1][r]; }
-          if (m < g.M) epi_chunk<bf16, CF>(g, CF, m, n0 + wc * 96 + 32 * t + 8 * fg, v, hw);
+          const int n = n0 + wc * 96 + 32 * t + 8 * fg;
+          if (CF & SODT_EPI_BIAS) {
+            const u32x4 b0 = lds_rd128<0>(lbase + T3_BIASOFF + 4 * n), b1 = lds_rd128<16>(lbase + T3_BIASOFF + 4 * n);
+            T3_LGKM0();
+            v[0] += __uint_as_float(b0.x); v[1] += __uint_as_float(b0.y); v[2] += __uint_as_float(b0.z); v[3] += __uint_as_float(b0.w);
+            v[4] += __uint_as_float(b1.x); v[5] += __uint_as_float(b1.y); v[6] += __uint_as_float(b1.z); v[7] += __uint_as_float(b1.w);
+          }
+          if (m < g.M) epi_chunk<bf16, (CF & ~SODT_EPI_BIAS)>(g, CF & ~SODT_EPI_BIAS, m, n, v, hw);
           acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -595,7 +606,10 @@ bool sodt_nt3_eligible(const sodt_gemm_args* g) {
     default: return false;
   }
   if (g->oscatter || g->rmod > 0) return false;
-  if (g->N % T3_BN || g->K % T3_BK || g->K < 384 || g->M < T3_BM) return false;
+  // K = 192 (three K-steps per tile) only without epilogue loads: those drain the DMA queue once per tile
+  const bool loads = (g->flags & (SODT_EPI_RESID | SODT_EPI_DGELU)) != 0;
+  if (g->N % T3_BN || g->K % T3_BK || g->K < (loads ? 384 : 192) || g->M < T3_BM) return false;
+  if ((g->flags & SODT_EPI_BIAS) && g->N > T3_MAXBIAS) return false;
   if ((g->ldw % 8) || (g->ldc % 8)) return false;
   for (int i = 0; i < g->a.nseg; ++i)
     if (g->a.s[i].klen % T3_BK) return false;

@@ -120,7 +120,7 @@ def test_gemm_nt_pipelined_bf16(ops, dev):
     for, a row tail, more tiles than workgroups (persistent walk), multi-segment and conv-tap A operands."""
     dt = torch.bfloat16
     ops.gemm_set_variant(0)
-    for (M, N, K) in [(256 * 130 + 100, 384, 768), (1000, 192, 384), (4096, 1152, 1536)]:
+    for (M, N, K) in [(256 * 130 + 100, 384, 768), (1000, 192, 384), (4096, 1152, 1536), (70000, 576, 192), (3000, 768, 192)]:
         A = rnd((M, K), dev, dt, 1)
         W = rnd((N, K), dev, dt, 2, 1 / math.sqrt(K))
         bias = rnd((N,), dev, torch.float32, 3)
