@@ -167,7 +167,7 @@ def main():
                        "parallelism": f"dp{world}"},
             "model_tflops": round(img_s * FLOP_PER_IMG_1024 * (S / 1024) ** 2 / 1e12, 1),
             # the launch with the most flops AND bytes of the step; AI = 85 flop/B << ridge (~400), so it is priced against HBM
-            "roofline": {"bound": "hbm", "kernel": "gemm_bs_kernel<%s> stage-1 fc1 (M=%d,N=768,K=192, bias + GELU dual store)" % (a.dtype, Mrows),
+            "roofline": {"bound": "hbm", "kernel": "%s stage-1 fc1 (M=%d,N=768,K=192, bias + GELU dual store)" % ("gemm_nt3_kernel<bias|gelu_dual> (bf16, LDS-DMA pipelined)" if a.dtype == "bf16" else "gemm_bs_kernel<f32>", Mrows),
                          "achieved": round(achieved, 1), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(achieved / PEAK_HBM, 4),
                          "avg_launch_ms": round(kern_ms, 4), "algorithmic_bytes": alg_bytes,
                          "tflops": round(flops / (kern_ms * 1e-3) / 1e12, 1), "traffic": traffic},
