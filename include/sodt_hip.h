@@ -93,6 +93,10 @@ typedef struct {
   int M, N, K;
   int kperm_c, kperm_t;         /* if kperm_t > 1: column k = tap*C + ci is stored at ci*T + tap (torch conv layout) */
   int splits;                   /* M is cut into this many slices (grid.y) */
+  float* partial;               /* optional f32 scratch of >= splits*N*K floats (16-byte aligned): the bf16 pipelined kernel then
+                                 * writes one partial tile per slice with plain stores and a second kernel adds their sum to dW,
+                                 * instead of splits*N*K contended atomics.  NULL / too small: atomics */
+  long partial_floats;
 } sodt_gemm_tn_args;
 
 /* dW += dY^T @ X (+ dbias): every weight gradient of the path (autograd of the

@@ -48,7 +48,8 @@ class GemmTnArgs(C.Structure):
                 ("dW", C.c_void_p), ("lddw", C.c_int),
                 ("dbias", C.c_void_p),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
-                ("kperm_c", C.c_int), ("kperm_t", C.c_int), ("splits", C.c_int)]
+                ("kperm_c", C.c_int), ("kperm_t", C.c_int), ("splits", C.c_int),
+                ("partial", C.c_void_p), ("partial_floats", C.c_long)]
 
 
 class PrepDesc(C.Structure):

@@ -518,6 +518,8 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const sodt_gemm_tn_args g
   if (!wave_live) return;
 
   // acc[i][j][r]: P column P0 + wr*64 + 16 i + 4 fg + r, Q column Q0 + wc*96 + 16 j + fr
+  // with a scratch: this slice's partial tile goes to part[n][k] (natural k order) with plain stores
+  float* part = g.partial ? g.partial + (long)split * g.N * g.K : nullptr;
   if (!SWAP) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -530,7 +532,10 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const sodt_gemm_tn_args g
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = P0 + wr * 64 + 16 * i + 4 * fg + r;
-          if (n < Pdim) atomicAdd(g.dW + (long)n * g.lddw + k, acc[i][j][r]);
+          if (n < Pdim) {
+            if (part) part[(long)n * g.K + qc] = acc[i][j][r];
+            else atomicAdd(g.dW + (long)n * g.lddw + k, acc[i][j][r]);
+          }
         }
       }
   } else {
@@ -550,7 +555,10 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const sodt_gemm_tn_args g
       for (int nn = fg; nn < 96; nn += 4) {
         const int n = Q0 + wc * 96 + nn;
         const float v = patch[nn * 17 + fr];
-        if (pc < Pdim && n < Qdim) atomicAdd(g.dW + (long)n * g.lddw + k, v);
+        if (pc < Pdim && n < Qdim) {
+          if (part) part[(long)n * g.K + pc] = v;
+          else atomicAdd(g.dW + (long)n * g.lddw + k, v);
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -578,6 +586,32 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const sodt_gemm_tn_args g
   }
 }
 
+// dW[n][perm(k)] += sum over slices of partial[s][n][k]; four consecutive k per thread
+__global__ __launch_bounds__(256) void tn3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int N, int K,
+                                                        int lddw, int splits, int kperm_c, int kperm_t) {
+  const long nk4 = (long)N * K / 4;
+  const long slice = (long)N * K;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nk4; i += (long)gridDim.x * 256) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* p = partial + i * 4;
+    for (int s = 0; s < splits; ++s) {
+      const float4 v = *(const float4*)(p + s * slice);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    const int n = (int)((i * 4) / K), k0 = (int)((i * 4) - (long)n * K);
+    float* d = dW + (long)n * lddw;
+    if (kperm_t > 1) {
+      const float vv[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int k = k0 + j; d[(k % kperm_c) * kperm_t + k / kperm_c] += vv[j]; }
+    } else {
+      float4 o = *(float4*)(d + k0);
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      *(float4*)(d + k0) = o;
+    }
+  }
+}
+
 template <bool SWAP, bool SPATIAL>
 int launch_tn3(const sodt_gemm_tn_args* g, hipStream_t st) {
   static bool attr_set = false;
@@ -590,7 +624,20 @@ int launch_tn3(const sodt_gemm_tn_args* g, hipStream_t st) {
   }
   const int Pdim = SWAP ? g->K : g->N, Qdim = SWAP ? g->N : g->K;
   const long tiles = (long)((Pdim + 255) / 256) * ((Qdim + 191) / 192);
-  hipLaunchKernelGGL((gemm_tn3_kernel<SWAP, SPATIAL>), dim3((unsigned)(tiles * g->splits)), dim3(512), N5_LDS, st, *g);
+  sodt_gemm_tn_args a = *g;
+  const bool use_partial = a.partial && a.splits > 1 && (long)a.splits * a.N * a.K <= a.partial_floats &&
+                           ((uintptr_t)a.partial & 15) == 0 && (a.lddw % 4) == 0 && ((uintptr_t)a.dW & 15) == 0;
+  if (!use_partial) a.partial = nullptr;
+  hipLaunchKernelGGL((gemm_tn3_kernel<SWAP, SPATIAL>), dim3((unsigned)(tiles * a.splits)), dim3(512), N5_LDS, st, a);
+  if (use_partial) {
+    // slices past the end of M launch no work and write no partial tile: the reduction reads only the live ones
+    const long rows_per = ((((long)a.M + a.splits - 1) / a.splits) + N5_ROWS - 1) / N5_ROWS * N5_ROWS;
+    const int live = (int)(((long)a.M + rows_per - 1) / rows_per);
+    const long nk4 = (long)a.N * a.K / 4;
+    const int blocks = (int)((nk4 + 255) / 256 < 2048 ? (nk4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(tn3_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a.partial, a.dW, a.N, a.K, a.lddw,
+                       live, a.kperm_c, a.kperm_t);
+  }
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 

@@ -89,6 +89,9 @@ class Engine:
         # anchor that makes the autograd node require grad even if the caller froze everything else
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
         self.ddp = None     # set by ddp.attach()
+        # 64 MiB of f32 for the per-slice partial tiles of the bf16 weight-gradient GEMMs (largest need: 12.5 M floats)
+        self._tn_scratch = torch.empty(16 << 20, dtype=torch.float32, device=self.dev)
+        ops.set_tn_scratch(self._tn_scratch)
 
     # ------------------------------------------------------------------ structure checks
     def _check_head(self):

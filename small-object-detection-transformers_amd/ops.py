@@ -185,6 +185,17 @@ def tn_splits(M: int, N: int, K: int, bf16: bool = False) -> int:
     return max(1, min(M // 256 if M >= 256 else 1, max(1, slots // tiles)))
 
 
+_tn_scratch: Optional[torch.Tensor] = None
+
+
+def set_tn_scratch(t: Optional[torch.Tensor]) -> None:
+    """f32 device scratch for the weight-gradient partial tiles (sodt_gemm_tn_args.partial); kept alive here because
+    recorded launch plans hold its address."""
+    global _tn_scratch
+    assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    _tn_scratch = t
+
+
 def gemm_tn(dY: torch.Tensor, segs: Sequence[SegSpec], dW: torch.Tensor, M: int, N: int, K: int, *,
             ldy: Optional[int] = None, y_off: int = 0, spatial: Optional[Tuple[int, int]] = None,
             dbias: Optional[torch.Tensor] = None, lddw: Optional[int] = None, kperm: Optional[Tuple[int, int]] = None,
@@ -202,6 +213,8 @@ def gemm_tn(dY: torch.Tensor, segs: Sequence[SegSpec], dW: torch.Tensor, M: int,
     if kperm is not None:
         g.kperm_c, g.kperm_t = kperm
     g.splits = tn_splits(M, N, K, dY.dtype == torch.bfloat16) if splits is None else splits
+    if _tn_scratch is not None and _tn_scratch.device == dY.device and g.splits > 1:
+        g.partial, g.partial_floats = _tn_scratch.data_ptr(), _tn_scratch.numel()
     _launch("sodt_gemm_tn", C.byref(g), dt_code(dY))
 
 

@@ -293,12 +293,15 @@ def test_gemm_tn_pipelined_bf16(ops, dev):
                               (4096, 1152, 384, 5), (2000, 136, 200, 2), (8192, 1536, 384, None), (1024, 64, 64, 1)]:
         dY = rnd((M, N), dev, dt, 1)
         X = rnd((M, K), dev, dt, 2)
-        dW = torch.ones(N, K, device=dev, dtype=torch.float32)
-        db = torch.ones(N, device=dev, dtype=torch.float32)
-        ops.gemm_tn(dY, [ops.SegSpec(X)], dW, M, N, K, dbias=db, splits=splits)
         ref = dY.float().double().t() @ X.float().double()
-        close(dW - 1, ref, dt, what=f"tn3 dW {M}x{N}x{K}")
-        close(db - 1, dY.float().double().sum(0), dt, what=f"tn3 dbias {M}x{N}x{K}")
+        for scratch in (None, torch.full((4 << 20,), float("nan"), device=dev)):   # atomics, then per-slice partial tiles
+            ops.set_tn_scratch(scratch)
+            dW = torch.ones(N, K, device=dev, dtype=torch.float32)
+            db = torch.ones(N, device=dev, dtype=torch.float32)
+            ops.gemm_tn(dY, [ops.SegSpec(X)], dW, M, N, K, dbias=db, splits=splits)
+            close(dW - 1, ref, dt, what=f"tn3 dW {M}x{N}x{K} scratch={scratch is not None}")
+            close(db - 1, dY.float().double().sum(0), dt, what=f"tn3 dbias {M}x{N}x{K}")
+        ops.set_tn_scratch(None)
     # 2x2 conv weight gradient, C = 192 (stage-1 conv MLP), torch (Co, Ci, 2, 2) layout via kperm
     B, H, Wd, Ci, Co = 2, 24, 40, 192, 192
     x = rnd((B, Ci, H, Wd), dev, dt, 3)
@@ -307,9 +310,12 @@ def test_gemm_tn_pipelined_bf16(ops, dev):
     F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w2).backward(dy_.float())
     xt, dyt = _nhwc(x), _nhwc(dy_)
     segs = [ops.SegSpec(xt, Ci, 0, dy, dx, 1, 0, H, Wd) for dy in (0, 1) for dx in (0, 1)]
-    dW = torch.zeros(Co, Ci, 2, 2, device=dev, dtype=torch.float32)
-    ops.gemm_tn(dyt, segs, dW, B * H * Wd, Co, 4 * Ci, spatial=(H, Wd), kperm=(Ci, 4))
-    close(dW, w2.grad, dt, what="tn3 conv2x2 dW")
+    for scratch in (None, torch.full((4 << 20,), float("nan"), device=dev)):
+        ops.set_tn_scratch(scratch)
+        dW = torch.zeros(Co, Ci, 2, 2, device=dev, dtype=torch.float32)
+        ops.gemm_tn(dyt, segs, dW, B * H * Wd, Co, 4 * Ci, spatial=(H, Wd), kperm=(Ci, 4))
+        close(dW, w2.grad, dt, what="tn3 conv2x2 dW")
+    ops.set_tn_scratch(None)
     # 3x3 conv (head) with a two-tensor concat input
     Ci1, Ci2, Co = 64, 128, 128
     x1 = rnd((B, Ci1, H, Wd), dev, dt, 6)
