@@ -219,10 +219,32 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   issue_b(0);
   issue_a(1);
   int a_slot = 0, b_slot = 0, c_ord = 0, c_kt = 0;
+  // epilogue operand (residual / GELU input) of the tile being finished: fetched with inline-asm loads at the START of
+  // the tile's last K-step, ahead of that step's DMA issues, so it lands under the MFMAs and is waited for with a
+  // counted vmcnt(7); a compiler-visible load in the epilogue would wait vmcnt(0) and drain the DMA queue every tile
+  constexpr bool PRE = (CF & (SODT_EPI_RESID | SODT_EPI_DGELU)) != 0;
+  u32x4 pre[4][3];
   for (int s = 0; s < total; ++s) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // everything but the newest A stage has landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (PRE && c_kt == nk - 1) {
+      const int t_ = lw + c_ord * G;
+      const long m0 = (long)(t_ / ntn) * T3_BM;
+      const int n0 = (t_ % ntn) * T3_BN;
+      const bf16* base = (CF & SODT_EPI_RESID) ? (const bf16*)g.R : (const bf16*)g.aux;
+      const int ldp = (CF & SODT_EPI_RESID) ? g.ldr : g.ldaux;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        long m = m0 + wr * 64 + 16 * u + fi;
+        if (m >= g.M) m = g.M - 1;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const bf16* ptr = base + m * ldp + n0 + wc * 96 + 32 * t + 8 * fg;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre[u][t]) : "v"(ptr) : "memory");
+        }
+      }
+    }
     issue_b(b_slot ^ 1);
     issue_a(a_slot == 0 ? 2 : a_slot - 1);                // (s + 2) % 3
     const uint32_t ao = a_slot * T3_AST, bo = b_slot * T3_BST;
@@ -248,7 +270,8 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
       mma_sw(acc[3][2][0], fw4, fa3); mma_sw(acc[3][2][1], fw5, fa3);                \
     }
     T3_KB(aRd0, wRd0)
-    T3_KB(aRd1, wRd1)
+    if (PRE) __builtin_amdgcn_sched_barrier(0);   // keep the second half's fragment reads behind the first half's MFMAs:
+    T3_KB(aRd1, wRd1)                             //  frees ~40 VGPRs for the prefetched epilogue operand (no spills)
 #undef T3_KB
     a_slot = a_slot == 2 ? 0 : a_slot + 1;
     b_slot ^= 1;
@@ -258,6 +281,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
       const int t_ = lw + c_ord * G;
       const long m0 = (long)(t_ / ntn) * T3_BM;
       const int n0 = (t_ % ntn) * T3_BN;
+      if (PRE) { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long m = m0 + wr * 64 + 16 * u + fi;
@@ -267,13 +291,24 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { v[r] = acc[u][t][0][r]; v[4 + r] = acc[u][t][1][r]; }
           const int n = n0 + wc * 96 + 32 * t + 8 * fg;
+          if (PRE) {
+            float x[8];
+            uint4 pu; pu.x = pre[u][t].x; pu.y = pre[u][t].y; pu.z = pre[u][t].z; pu.w = pre[u][t].w;
+            unpack<bf16>(pu, x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (CF & SODT_EPI_DGELU) v[j] *= dgelu_f(x[j]);     // same order as epi_chunk: (bias, dgelu, resid)
+              else v[j] += x[j];
+            }
+          }
           if (CF & SODT_EPI_BIAS) {
             const u32x4 b0 = lds_rd128<0>(lbase + T3_BIASOFF + 4 * n), b1 = lds_rd128<16>(lbase + T3_BIASOFF + 4 * n);
             T3_LGKM0();
             v[0] += __uint_as_float(b0.x); v[1] += __uint_as_float(b0.y); v[2] += __uint_as_float(b0.z); v[3] += __uint_as_float(b0.w);
             v[4] += __uint_as_float(b1.x); v[5] += __uint_as_float(b1.y); v[6] += __uint_as_float(b1.z); v[7] += __uint_as_float(b1.w);
           }
-          if (m < g.M) epi_chunk<bf16, (CF & ~SODT_EPI_BIAS)>(g, CF & ~SODT_EPI_BIAS, m, n, v, hw);
+          constexpr int CF2 = CF & ~(SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_DGELU);
+          if (m < g.M) epi_chunk<bf16, CF2>(g, CF2, m, n, v, hw);
           acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -653,9 +688,9 @@ bool sodt_nt3_eligible(const sodt_gemm_args* g) {
     default: return false;
   }
   if (g->oscatter || g->rmod > 0) return false;
-  // K = 192 (three K-steps per tile) only without epilogue loads: those drain the DMA queue once per tile
-  const bool loads = (g->flags & (SODT_EPI_RESID | SODT_EPI_DGELU)) != 0;
-  if (g->N % T3_BN || g->K % T3_BK || g->K < (loads ? 384 : 192) || g->M < T3_BM) return false;
+  if (g->N % T3_BN || g->K % T3_BK || g->K < 192 || g->M < T3_BM) return false;
+  if ((g->flags & SODT_EPI_RESID) && (g->ldr % 8)) return false;
+  if ((g->flags & SODT_EPI_DGELU) && (g->ldaux % 8)) return false;
   if ((g->flags & SODT_EPI_BIAS) && g->N > T3_MAXBIAS) return false;
   if ((g->ldw % 8) || (g->ldc % 8)) return false;
   for (int i = 0; i < g->a.nseg; ++i)
