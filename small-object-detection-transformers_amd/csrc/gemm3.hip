@@ -621,18 +621,35 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const sodt_gemm_tn_args g
   }
 }
 
-// dW[n][perm(k)] += sum over slices of partial[s][n][k]; four consecutive k per thread
+// dW[n][perm(k)] += sum over slices of partial[s][n][k]: 64 float4 columns per workgroup, the slices dealt over its
+// four waves (independent 16-byte loads, four in flight per thread) and combined through LDS
 __global__ __launch_bounds__(256) void tn3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int N, int K,
                                                         int lddw, int splits, int kperm_c, int kperm_t) {
+  __shared__ float4 red[4][64];
   const long nk4 = (long)N * K / 4;
   const long slice = (long)N * K;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nk4; i += (long)gridDim.x * 256) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int c = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + c;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < nk4) {
     const float* p = partial + i * 4;
-    for (int s = 0; s < splits; ++s) {
-      const float4 v = *(const float4*)(p + s * slice);
+    int s = sg;
+    for (; s + 12 < splits; s += 16) {
+      const float4 v0 = *(const float4*)(p + (long)s * slice), v1 = *(const float4*)(p + (long)(s + 4) * slice);
+      const float4 v2 = *(const float4*)(p + (long)(s + 8) * slice), v3 = *(const float4*)(p + (long)(s + 12) * slice);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < splits; s += 4) {
+      const float4 v = *(const float4*)(p + (long)s * slice);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+  }
+  red[sg][c] = a;
+  __syncthreads();
+  if (sg == 0 && i < nk4) {
+    const float4 b1 = red[1][c], b2 = red[2][c], b3 = red[3][c];
+    a.x += b1.x + b2.x + b3.x; a.y += b1.y + b2.y + b3.y; a.z += b1.z + b2.z + b3.z; a.w += b1.w + b2.w + b3.w;
     const int n = (int)((i * 4) / K), k0 = (int)((i * 4) - (long)n * K);
     float* d = dW + (long)n * lddw;
     if (kperm_t > 1) {
@@ -669,7 +686,7 @@ int launch_tn3(const sodt_gemm_tn_args* g, hipStream_t st) {
     const long rows_per = ((((long)a.M + a.splits - 1) / a.splits) + N5_ROWS - 1) / N5_ROWS * N5_ROWS;
     const int live = (int)(((long)a.M + rows_per - 1) / rows_per);
     const long nk4 = (long)a.N * a.K / 4;
-    const int blocks = (int)((nk4 + 255) / 256 < 2048 ? (nk4 + 255) / 256 : 2048);
+    const int blocks = (int)((nk4 + 63) / 64);
     hipLaunchKernelGGL(tn3_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a.partial, a.dW, a.N, a.K, a.lddw,
                        live, a.kperm_c, a.kperm_t);
   }
