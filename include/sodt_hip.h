@@ -58,7 +58,10 @@ typedef struct {
 #define SODT_EPI_RESID 2         /* + R[m % rmod or m][n] */
 #define SODT_EPI_GELU_DUAL 4     /* C = pre-activation, C2 = GELU(erf) of it */
 #define SODT_EPI_DGELU 8         /* value *= gelu'(aux[m][n]) */
-#define SODT_EPI_STATS 16        /* stats[0][n] += sum_m v, stats[1][n] += sum_m v*v (f64 atomics) */
+#define SODT_EPI_STATS 16        /* stats[r][0][n] += sum_m v, stats[r][1][n] += sum_m v*v (f64 atomics); the buffer holds
+                                  * SODT_STATS_REPL replicas r of [2][N] (workgroups spread over them: same-address atomics
+                                  * serialise in L2); sodt_bn_finalize sums the replicas */
+#define SODT_STATS_REPL 16
 #define SODT_EPI_AFFINE_SILU 32  /* v = silu(v*scale[n] + shift[n])  (fused / eval-mode Conv) */
 #define SODT_EPI_DETECT 64       /* store f32 to (B, na, HW, no): Detect's view+permute */
 #define SODT_EPI_OUT_F32 128     /* C is float regardless of dtype */
@@ -156,7 +159,7 @@ int sodt_cross_attn_ln_bwd(const float* e, const float* gamma, const void* dout,
                            float* dbeta, int B, int S, int ws, int shift, int dtype, sodt_stream_t st);
 
 /* BatchNorm2d (eps 1e-3, momentum 0.03) + SiLU of the head's Conv (common.py:38-50,
- * torch_utils.py:150-152), token-major.  stats f64 [2][C] from SODT_EPI_STATS.
+ * torch_utils.py:150-152), token-major.  stats f64 [SODT_STATS_REPL][2][C] from SODT_EPI_STATS.
  * finalize: mean/rstd (f32 [2][C]) + running-stat update (unbiased var); stats == NULL
  * takes mean/rstd from the running statistics (eval). */
 int sodt_bn_finalize(const double* stats, float* mean_rstd, float* running_mean, float* running_var,

@@ -448,18 +448,29 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
 // ---------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------
-// delta[tok][head] = sum_d dO * O   (needed only when a window has more than one key tile)
+// delta[tok][head] = sum_d dO * O   (needed only when a window has more than one key tile).  One 16-byte chunk of
+// both tensors per lane, reduced over the hd / KPL lanes of a head with DPP-free xor shuffles: every byte is read once.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o,
                                                         float* __restrict__ delta, long M, int C, int heads) {
-  const int hd = C / heads;
-  const long total = M * heads;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long tok = i / heads; const int h = (int)(i - tok * heads);
-    const T* a = o + tok * C + h * hd; const T* bb = d_o + tok * C + h * hd;
+  constexpr int KPL = TT<T>::KPL;
+  const int cpr = C / KPL;                 // chunks per token row
+  const int cph = cpr / heads;             // chunks (= lanes) per head: a power of two <= 16
+  const long total = M * cpr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (total + 63) / 64 * 64; i += (long)gridDim.x * 256) {
     float s = 0.f;
-    for (int j = 0; j < hd; ++j) s += to_f(a[j]) * to_f(bb[j]);
-    delta[i] = s;
+    if (i < total) {
+      float a[KPL], b[KPL];
+      unpack<T>(*(const uint4*)(o + i * KPL), a);
+      unpack<T>(*(const uint4*)(d_o + i * KPL), b);
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) s = fmaf(a[j], b[j], s);
+    }
+    for (int w = 1; w < cph; w <<= 1) s += __shfl_xor(s, w);
+    if (i < total && (i % cph) == 0) {
+      const long tok = i / cpr; const int h = (int)(i - tok * cpr) / cph;
+      delta[tok * heads + h] = s;
+    }
   }
 }
 
@@ -947,7 +958,7 @@ extern "C" int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const 
   hipStream_t st = (hipStream_t)st_;
   const int hd = C / heads;
   if (dtype == SODT_BF16) {
-    if (hd == 16) return launch_bwd<bf16, 16, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
+    if (hd == 16) return launch_bwd<bf16, 16, 4>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
     if (hd == 32) return launch_bwd<bf16, 32, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
     if (hd == 64) return launch_bwd<bf16, 64, 1>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
   } else if (dtype == SODT_F32) {

@@ -179,8 +179,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
         const float v = sC[r * EPI_LD + tid];
         s += v; s2 += (double)v * v;
       }
-      atomicAdd(g.stats + n0 + tid, s);
-      atomicAdd(g.stats + g.N + n0 + tid, s2);
+      double* st = g.stats + (size_t)(blockIdx.x % SODT_STATS_REPL) * 2 * g.N;
+      atomicAdd(st + n0 + tid, s);
+      atomicAdd(st + g.N + n0 + tid, s2);
     }
   }
 
@@ -602,8 +603,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g,
         const float a = group16_sum(st1[p][j]), b = group16_sum(st2[p][j]);
         const int n = n0 + wc * (BN_ / 2) + p * 32 + 8 * fg + j;
         if (fr == 0 && n < g.N) {
-          atomicAdd(g.stats + n, (double)a);
-          atomicAdd(g.stats + g.N + n, (double)b);
+          double* st = g.stats + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % SODT_STATS_REPL) * 2 * g.N;
+          atomicAdd(st + n, (double)a);
+          atomicAdd(st + g.N + n, (double)b);
         }
       }
   }

@@ -13,8 +13,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, float* __re
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   if (stats) {
-    const double mean = stats[c] / (double)count;
-    double var = stats[C + c] / (double)count - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < SODT_STATS_REPL; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
+    const double mean = s1 / (double)count;
+    double var = s2 / (double)count - mean * mean;
     if (var < 0.0) var = 0.0;
     mr[c] = (float)mean;
     mr[C + c] = (float)(1.0 / sqrt(var + (double)eps));

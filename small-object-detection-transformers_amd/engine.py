@@ -469,7 +469,7 @@ class Engine:
             ops.gemm_nt(segs, w[wname], y, M, Cout, K, spatial=spatial, affine=(ones, p[pname + "conv.bias"]))
         elif plan.training:
             z = plan.buf(tag + ".z", (M, Cout))
-            stats = plan.buf(tag + ".stats", (2, Cout), torch.float64)
+            stats = plan.buf(tag + ".stats", (L.STATS_REPL, 2, Cout), torch.float64)
             mr = plan.buf(tag + ".mr", (2, Cout), torch.float32)
             ops.zero_(stats)
             ops.gemm_nt(segs, w[wname], z, M, Cout, K, spatial=spatial, stats=stats)

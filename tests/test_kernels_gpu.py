@@ -89,11 +89,11 @@ def test_gemm_nt_stats_affine_detect(ops, dev, dt, variant):
     A = rnd((M, K), dev, dt, 1)
     W = rnd((N, K), dev, dt, 2, 1 / math.sqrt(K))
     out = torch.zeros(M, N, device=dev, dtype=dt)
-    stats = torch.zeros(2, N, device=dev, dtype=torch.float64)
+    stats = torch.zeros(16, 2, N, device=dev, dtype=torch.float64)     # SODT_STATS_REPL replicas, summed by bn_finalize
     ops.gemm_nt([ops.SegSpec(A)], W, out, M, N, K, stats=stats)
     ref = (A.float() @ W.float().t()).double()
-    close(stats[0], ref.sum(0), dt, what="sum")
-    close(stats[1], (ref * ref).sum(0), dt, what="sumsq")
+    close(stats.sum(0)[0], ref.sum(0), dt, what="sum")
+    close(stats.sum(0)[1], (ref * ref).sum(0), dt, what="sumsq")
     sc = rnd((N,), dev, torch.float32, 7).abs() + 0.5
     sh = rnd((N,), dev, torch.float32, 8)
     ops.gemm_nt([ops.SegSpec(A)], W, out, M, N, K, affine=(sc, sh))
@@ -498,7 +498,9 @@ def test_bn_silu(ops, dev, dt, Cc):
     g = rnd((Cc,), dev, torch.float32, 2) * 0.2 + 1
     b = rnd((Cc,), dev, torch.float32, 3) * 0.2
     zd = z.float().double()
-    stats = torch.stack([zd.sum(0), (zd * zd).sum(0)])
+    stats = torch.zeros(16, 2, Cc, device=dev, dtype=torch.float64)     # SODT_STATS_REPL replicas: split the sums over two of them
+    stats[3] = torch.stack([zd[:1000].sum(0), (zd[:1000] * zd[:1000]).sum(0)])
+    stats[11] = torch.stack([zd[1000:].sum(0), (zd[1000:] * zd[1000:]).sum(0)])
     mr = torch.zeros(2, Cc, device=dev)
     rm = torch.zeros(Cc, device=dev)
     rv = torch.ones(Cc, device=dev)

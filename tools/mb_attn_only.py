@@ -1,6 +1,28 @@
+"""Window-attention fwd / bwd timings at the bench shapes with an L2/MALL flush between calls (in-step conditions)."""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tools.microbench import attn
-attn(8, 256, 192, 8, 2)
+ops = importlib.import_module("small-object-detection-transformers_amd.ops")
+dev = torch.device("cuda:0"); dt = torch.bfloat16
+big = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+def timeit(fn, n=6):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+tz = timeit(lambda: big.zero_())
+def attn(B, H, Cc, ws, shift, heads=12):
+    M = B * H * H; L2 = 2 * ws - 1
+    qkv = torch.randn(M, 3 * Cc, device=dev).to(dt); bt = torch.randn(heads, L2 * L2, device=dev) * 0.1
+    out = torch.empty(M, Cc, device=dev, dtype=dt); lse = torch.empty(M, heads, device=dev)
+    def f(): big.zero_(); ops.window_attn_fwd(qkv, bt, out, lse, B, H, H, Cc, heads, ws, shift)
+    ms = timeit(f) - tz
+    dout = torch.randn(M, Cc, device=dev).to(dt); dqkv = torch.empty_like(qkv); dbt = torch.zeros_like(bt)
+    scr = torch.zeros(M * (Cc + heads), device=dev) if ws * ws > 64 else None
+    def b(): big.zero_(); ops.window_attn_bwd(qkv, bt, out, dout, lse, dqkv, dbt, scr, B, H, H, Cc, heads, ws, shift)
+    ms2 = timeit(b) - tz
+    print(f"attn C={Cc} H={H} ws={ws} shift={shift}: fwd {ms:7.3f} ms ({M*Cc*4*2/ms/1e6:6.0f} GB/s alg)  bwd {ms2:7.3f} ms ({M*Cc*8*2/ms2/1e6:6.0f} GB/s alg)", flush=True)
+attn(8, 256, 192, 8, 0); attn(8, 256, 192, 8, 4); attn(8, 128, 384, 8, 4); attn(8, 64, 768, 32, 16); attn(8, 64, 768, 8, 0); attn(8, 32, 768, 8, 0)
