@@ -856,6 +856,275 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------
+// backward, 8x8 windows (one 64-token tile per window), register-resident P / dS.
+//
+// S = Q K^T and dP = dO V^T leave the accumulators with four consecutive QUERIES per lane for one key, which is
+// exactly the A-operand layout of the query contractions dV += P^T dO and dK += dS^T Q: two 16-query strips packed
+// to bf16 form one 32-deep MFMA operand (the B operands dO / Q are read with the transposing LDS load from rows in
+// the same strip-pair order; f32: one strip = one operand).  Only dQ = dS K contracts over keys: dS goes through a
+// 2.5 KiB per-wave [key][16 q] patch, one strip at a time.  No 64 x 64 P^T / dS^T tiles: LDS per wave drops from
+// 30 KiB to 15 KiB (hd 16) and the phase barriers disappear, so twice as many waves are resident per CU.
+// Everything else (persistent walk over the windows of a head group, register prefetch of the next window, bias
+// values and bias-gradient sums in registers, staged coalesced stores) is as in attn_bwd_kernel<FAST>.
+// ---------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ uint4 fragTp(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane);
+template <> __device__ __forceinline__ uint4 fragTp<bf16>(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane) {
+  // k-slots j < 4 <-> row 32 kbq + 4 g + j (even strip), j >= 4 <-> row 32 kbq + 16 + 4 g + (j - 4) (odd strip)
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned char* a = tile + (32 * kbq + 4 * g + q) * rowbytes + (col0 + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  union { s16x4 v; uint2 u; } lo, hi;
+  lo.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  hi.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 16 * rowbytes));
+  return make_uint4(lo.u.x, lo.u.y, hi.u.x, hi.u.y);
+}
+template <> __device__ __forceinline__ uint4 fragTp<float>(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane) {
+  return fragT<float>(tile, rowbytes, 16 * kbq, col0, lane);
+}
+
+template <typename T, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
+                                                                const T* __restrict__ d_out, const float* __restrict__ lse,
+                                                                T* __restrict__ dqkv, float* __restrict__ dbias_t,
+                                                                const AttnGeo g, int nwin_total) {
+  using L = Lay<T, HD>;
+  constexpr int E = L::E, KPL = L::KPL, NT = NW * 64, CPR = NW * L::DCH, NPF = L::DCH, MK = TT<T>::MMA_K;
+  constexpr int SPK = MK / 16;                  // 16-query strips per MFMA k-block: 2 (bf16) or 1 (f32)
+  constexpr int DSROW = 16 * E + 16;            // [key][16 q] patch row (bytes)
+  constexpr int LTMAX = 225;
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE], sK[NW * L::QTILE], sV[NW * L::QTILE],
+      sDO[NW * L::QTILE];
+  __shared__ __attribute__((aligned(16))) unsigned char sDS[NW * 64 * DSROW];
+  __shared__ __attribute__((aligned(16))) unsigned char sDQ[NW * L::QTILE];      // dQ staging (Q stays live to the end)
+  __shared__ float sDB[NW][LTMAX + 3];
+  __shared__ float sLse[NW][64];
+  __shared__ int sTokQ[64];
+  __shared__ short sGeoQ[64][4];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int hg = blockIdx.y, head = hg * NW + w;
+  const int C3 = 3 * g.C, L2 = 2 * g.ws - 1;
+  const int R = 64 / g.ws, LT = (2 * R - 1) * L2;
+  const float scale = rsqrtf((float)HD), scale2 = scale * SODT_LOG2E;
+  const float* bt = bias_t + (long)head * L2 * L2;
+  unsigned char* myQ = sQ + w * L::QTILE; unsigned char* myK = sK + w * L::QTILE;
+  unsigned char* myV = sV + w * L::QTILE; unsigned char* myDO = sDO + w * L::QTILE;
+  unsigned char* myDS = sDS + w * 64 * DSROW;
+  unsigned char* myDQ = sDQ + w * L::QTILE;
+  for (int i = tid; i < NW * (LTMAX + 3); i += NT) (&sDB[0][0])[i] = 0.f;
+
+  // 8x8 windows: a 16-token strip is two window rows, so the table entry of (q, key) depends on the strips only
+  // through ms - ns:  qy - ky = 2 (ms - ns) + ((4 fg + r) >> 3) - (fr >> 3),  qx - kx = ((4 fg + r) & 7) - (fr & 7).
+  // Bias values and bias-gradient sums are therefore kept per strip DIFFERENCE (7 x 4 registers each, not 64).
+  f32x4 dbc[7];
+  float bias2[7][4];
+#pragma unroll
+  for (int dc = 0; dc < 7; ++dc) {
+    dbc[dc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int dy = 2 * (dc - 3) + ((4 * fg + r) >> 3) - (fr >> 3), dx = ((4 * fg + r) & 7) - (fr & 7);
+      bias2[dc][r] = (dy > -8 && dy < 8) ? bt[(dy + 7) * L2 + dx + 7] * SODT_LOG2E : 0.f;
+    }
+  }
+
+  uint4 pq0, pq1, pq2, pq3, pk0, pk1, pk2, pk3, pv0, pv1, pv2, pv3, pd0, pd1, pd2, pd3;
+  float plse = 0.f;
+#define B2_ISSUE_ONE(i, ITEM)                                                           \
+  if constexpr (NPF > i) {                                                              \
+    int t_ = (ITEM);                                                                    \
+    const int wx_ = t_ % g.nwx; t_ /= g.nwx;                                            \
+    const int wy_ = t_ % g.nwy; const int b_ = t_ / g.nwy;                              \
+    const int idx = tid + i * NT;                                                       \
+    const int r = idx / CPR, cc = idx - r * CPR;                                        \
+    int row, rid, iy, ix;                                                               \
+    win_token(g, b_, wy_, wx_, r, row, rid, iy, ix);                                    \
+    const T* src = qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL;                    \
+    pq##i = *(const uint4*)(src); pk##i = *(const uint4*)(src + g.C); pv##i = *(const uint4*)(src + 2 * g.C); \
+    pd##i = *(const uint4*)(d_out + (long)row * g.C + (hg * NW) * HD + cc * KPL);       \
+  }
+#define B2_ISSUE(ITEM) {                                                                \
+    B2_ISSUE_ONE(0, ITEM) B2_ISSUE_ONE(1, ITEM) B2_ISSUE_ONE(2, ITEM) B2_ISSUE_ONE(3, ITEM) \
+    int t2_ = (ITEM);                                                                   \
+    const int wx2_ = t2_ % g.nwx; t2_ /= g.nwx;                                         \
+    const int wy2_ = t2_ % g.nwy; const int b2_ = t2_ / g.nwy;                          \
+    int row2, rid2, iy2, ix2;                                                           \
+    win_token(g, b2_, wy2_, wx2_, lane, row2, rid2, iy2, ix2);                          \
+    plse = lse[(long)row2 * g.heads + head];                                            \
+  }
+#define B2_STORE_ONE(i)                                                                 \
+  if constexpr (NPF > i) {                                                              \
+    const int idx = tid + i * NT;                                                       \
+    const int r = idx / CPR, cc = idx - r * CPR;                                        \
+    const int h = cc / L::DCH, dc = cc - h * L::DCH;                                    \
+    const int off = (h * 64 + r) * L::QROW + dc * 16;                                   \
+    *(uint4*)(sQ + off) = pq##i; *(uint4*)(sK + off) = pk##i; *(uint4*)(sV + off) = pv##i; *(uint4*)(sDO + off) = pd##i; \
+  }
+  B2_ISSUE((int)blockIdx.x < nwin_total ? (int)blockIdx.x : 0)
+
+  for (int item = blockIdx.x; item < nwin_total; item += gridDim.x) {
+    int t = item;
+    const int wx = t % g.nwx; t /= g.nwx;
+    const int wy = t % g.nwy; const int b = t / g.nwy;
+    const bool msk = g.shift > 0 && (wy == g.nwy - 1 || wx == g.nwx - 1);
+    __syncthreads();                                   // previous window's staged outputs are out
+    if (tid < 64) {
+      int row, rid, iy, ix;
+      win_token(g, b, wy, wx, tid, row, rid, iy, ix);
+      sTokQ[tid] = row; sGeoQ[tid][0] = (short)iy; sGeoQ[tid][1] = (short)ix; sGeoQ[tid][2] = (short)rid;
+    }
+    B2_STORE_ONE(0) B2_STORE_ONE(1) B2_STORE_ONE(2) B2_STORE_ONE(3)
+    sLse[w][lane] = plse * SODT_LOG2E;
+    __syncthreads();
+    {
+      const int nxt = item + (int)gridDim.x < nwin_total ? item + (int)gridDim.x : item;
+      B2_ISSUE(nxt)
+    }
+
+    f32x4 dk[4][HD / 16], dv[4][HD / 16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int d = 0; d < HD / 16; ++d) { dk[i][d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    int krid[4];
+#pragma unroll
+    for (int ns = 0; ns < 4; ++ns) krid[ns] = msk ? (int)sGeoQ[ns * 16 + fr][2] : 0;
+#pragma unroll
+    for (int kbq = 0; kbq < 4 / SPK; ++kbq) {
+      // B operands of the query contractions for this k-block (rows = the strip pair, transposed read)
+      uint4 fdo[HD / 16], fqq[HD / 16];
+#pragma unroll
+      for (int d = 0; d < HD / 16; ++d) {
+        fdo[d] = fragTp<T>(myDO, L::QROW, kbq, d * 16, lane);
+        fqq[d] = fragTp<T>(myQ, L::QROW, kbq, d * 16, lane);
+      }
+#pragma unroll
+      for (int hh = 0; hh < SPK; ++hh) {
+        const int ms = kbq * SPK + hh;
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) { s[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kb = 0; kb < L::KBQ; ++kb) {
+          const uint4 fq = frag<T>(myQ, L::QROW, ms * 16, kb, HD, lane);
+          const uint4 fo = frag<T>(myDO, L::QROW, ms * 16, kb, HD, lane);
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns) {
+            const uint4 fk = frag<T>(myK, L::QROW, ns * 16, kb, HD, lane);
+            const uint4 fv = frag<T>(myV, L::QROW, ns * 16, kb, HD, lane);
+            mma16<T>(s[ns], fq, fk);
+            mma16<T>(dp[ns], fo, fv);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qn = ms * 16 + fg * 4 + r;
+          const float lq = sLse[w][qn];
+          const int qrid = msk ? (int)sGeoQ[qn][2] : 0;
+          float dl = 0.f;
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns) {
+            float v = fmaf(s[ns][r], scale2, bias2[ms - ns + 3][r]);
+            if (msk && qrid != krid[ns]) v += -100.0f * SODT_LOG2E;
+            const float p = fast_exp2(v - lq);
+            s[ns][r] = p;
+            dl = fmaf(p, dp[ns][r], dl);
+          }
+          dl = group16_sum(dl);
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns) {
+            const float ds = s[ns][r] * (dp[ns][r] - dl);
+            dp[ns][r] = ds;
+            dbc[ms - ns + 3][r] += ds;
+          }
+        }
+        // this strip as (half of) the A operand of the query contractions: bf16 strips fill k-slots 0-3 (even strip) or
+        // 4-7 (odd strip) with zeros in the other half - twice the MFMAs of a packed pair (still < 2 % of the kernel),
+        // no operand registers held across strips.  dS strip -> [key][16 q] patch for dQ.
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) {
+          uint4 ap, ads;
+          if constexpr (std::is_same<T, bf16>::value) {
+            const uint32_t p01 = pack2bf(s[ns][0], s[ns][1]), p23 = pack2bf(s[ns][2], s[ns][3]);
+            const uint32_t d01 = pack2bf(dp[ns][0], dp[ns][1]), d23 = pack2bf(dp[ns][2], dp[ns][3]);
+            ap = hh == 0 ? make_uint4(p01, p23, 0u, 0u) : make_uint4(0u, 0u, p01, p23);
+            ads = hh == 0 ? make_uint4(d01, d23, 0u, 0u) : make_uint4(0u, 0u, d01, d23);
+            *(uint2*)(myDS + (ns * 16 + fr) * DSROW + 8 * fg) = make_uint2(d01, d23);
+          } else {
+            ap = make_uint4(__float_as_uint(s[ns][0]), __float_as_uint(s[ns][1]), __float_as_uint(s[ns][2]), __float_as_uint(s[ns][3]));
+            ads = make_uint4(__float_as_uint(dp[ns][0]), __float_as_uint(dp[ns][1]), __float_as_uint(dp[ns][2]), __float_as_uint(dp[ns][3]));
+            *(float4*)(myDS + (ns * 16 + fr) * DSROW + 16 * fg) = make_float4(dp[ns][0], dp[ns][1], dp[ns][2], dp[ns][3]);
+          }
+#pragma unroll
+          for (int d = 0; d < HD / 16; ++d) {
+            mma16<T>(dv[ns][d], ap, fdo[d]);
+            mma16<T>(dk[ns][d], ads, fqq[d]);
+          }
+        }
+        // dQ strip ms = dS K: A = dS[q = fr][keys] read transposed from the patch (same wave: LDS ops are in order),
+        // B = K read transposed from its tile; finished strips go straight to the dQ staging tile
+        f32x4 dq[HD / 16];
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < L::KBT; ++kb) {
+          const uint4 fst = fragT<T>(myDS, DSROW, kb * MK, 0, lane);
+#pragma unroll
+          for (int d = 0; d < HD / 16; ++d) mma16<T>(dq[d], fst, fragT<T>(myK, L::QROW, kb * MK, d * 16, lane));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int d = 0; d < HD / 16; ++d)
+            st_elem<T>(myDQ + (ms * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dq[d][r] * scale);
+      }
+    }
+    // ---- stage dQ / dK / dV through this head's own Q / K / V tiles, then coalesced stores
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) {
+          const int off = (i * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E;
+          st_elem<T>(myK + off, dk[i][d][r] * scale);
+          st_elem<T>(myV + off, dv[i][d][r]);
+        }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CPR; idx += NT) {
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int h = cc / L::DCH, dc = cc - h * L::DCH;
+      T* dst = dqkv + (long)sTokQ[r] * C3 + (hg * NW) * HD + cc * KPL;
+      const int off = (h * 64 + r) * L::QROW + dc * 16;
+      *(uint4*)(dst) = *(const uint4*)(sDQ + off);
+      *(uint4*)(dst + g.C) = *(const uint4*)(sK + off);
+      *(uint4*)(dst + 2 * g.C) = *(const uint4*)(sV + off);
+    }
+  }
+  // ---- bias gradient: one reduction for all the windows this wave handled (window-local geometry is the same
+  //      for every window): registers -> LDS table -> global atomics
+  __syncthreads();
+  if (nwin_total > (int)blockIdx.x) {
+#pragma unroll
+    for (int dc = 0; dc < 7; ++dc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int dy = 2 * (dc - 3) + ((4 * fg + r) >> 3) - (fr >> 3), dx = ((4 * fg + r) & 7) - (fr & 7);
+        if (dy > -8 && dy < 8) atomicAdd(&sDB[w][(dy + 7) * L2 + dx + 7], dbc[dc][r]);
+      }
+  }
+  __syncthreads();
+  for (int i = lane; i < LT; i += 64) {
+    const float v = sDB[w][i];
+    if (v != 0.f) atomicAdd(dbias_t + (long)head * L2 * L2 + i, v);
+  }
+#undef B2_ISSUE_ONE
+#undef B2_ISSUE
+#undef B2_STORE_ONE
+}
+
 bool make_geo(AttnGeo& g, int B, int H, int W, int C, int heads, int ws, int shift) {
   if (B <= 0 || H <= 0 || W <= 0 || ws <= 0 || (H % ws) || (W % ws) || heads <= 0 || (C % heads)) return false;
   if ((ws * ws) % 64) return false;
@@ -900,7 +1169,12 @@ int launch_bwd(const void* qkv, const float* bias_t, const void* out, const void
   const int nitems = nwin * g.nqt;
   int gx = nitems < 1024 ? nitems : 1024;
   constexpr bool PFOK = (4 * Lay<T, HD>::DCH <= 16);
-  if (PFOK && g.nqt == 1) {
+  if (PFOK && g.nqt == 1 && g.ws == 8) {
+    if constexpr (PFOK) {
+      hipLaunchKernelGGL((attn_bwd_fast2_kernel<T, HD, NW>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
+                         (const T*)qkv, bias_t, (const T*)dout, lse, (T*)dqkv, dbias_t, g, nwin);
+    }
+  } else if (PFOK && g.nqt == 1) {
     hipLaunchKernelGGL((attn_bwd_kernel<T, HD, NW, PFOK>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
                        (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin, 0);
   } else {
