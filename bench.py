@@ -7,7 +7,7 @@
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - the dominant kernel (stage-1 fc1 GEMM: most flops and most bytes of any launch; HBM-bound),
+  roofline     - the dominant kernel (stage-1 fc1 GEMM: the forward launch with the most flops; HBM-bound),
                  timed live with HIP events on the launch stream inside the timed region; `traffic` = PMC
                  FETCH_SIZE/WRITE_SIZE of the same kernel from the newest profiles/*_traffic.json
   cpu_baseline - the CPU oracle (oracle/ref_torch.py, a port) timed on this host's cores on a
@@ -148,9 +148,11 @@ def main():
         Mrows = B * t * t
         kern_ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
         flops = 2.0 * Mrows * 768 * 192
-        # algorithmic HBM bytes of this launch: per image t*t tokens x (192 in + 2 x 768 out) x 2 B (bf16), x B images
+        # algorithmic HBM bytes of this launch: per image t*t tokens x (192 in + 768 out) x 2 B (bf16), x B images; the
+        # f32 path also stores the pre-activation (dual store), the bf16 path recomputes it in backward
         es = 2 if a.dtype == "bf16" else 4
-        alg_bytes = Mrows * (192 + 2 * 768) * es + 768 * 192 * es + 768 * 4
+        nout = 1 if a.dtype == "bf16" else 2
+        alg_bytes = Mrows * (192 + nout * 768) * es + 768 * 192 * es + 768 * 4
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")) \
@@ -167,7 +169,7 @@ def main():
                        "parallelism": f"dp{world}"},
             "model_tflops": round(img_s * FLOP_PER_IMG_1024 * (S / 1024) ** 2 / 1e12, 1),
             # the launch with the most flops AND bytes of the step; AI = 85 flop/B << ridge (~400), so it is priced against HBM
-            "roofline": {"bound": "hbm", "kernel": "%s stage-1 fc1 (M=%d,N=768,K=192, bias + GELU dual store)" % ("gemm_nt3_kernel<bias|gelu_dual> (bf16, LDS-DMA pipelined)" if a.dtype == "bf16" else "gemm_bs_kernel<f32>", Mrows),
+            "roofline": {"bound": "hbm", "kernel": "%s stage-1 fc1 (M=%d,N=768,K=192, bias + GELU)" % ("gemm_nt3_kernel<bias|gelu> (bf16, LDS-DMA pipelined, activation-only store)" if a.dtype == "bf16" else "gemm_bs_kernel<f32> (dual store)", Mrows),
                          "achieved": round(achieved, 1), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(achieved / PEAK_HBM, 4),
                          "avg_launch_ms": round(kern_ms, 4), "algorithmic_bytes": alg_bytes,
                          "tflops": round(flops / (kern_ms * 1e-3) / 1e12, 1), "traffic": traffic},

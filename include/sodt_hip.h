@@ -64,7 +64,12 @@ typedef struct {
 #define SODT_STATS_REPL 16
 #define SODT_EPI_AFFINE_SILU 32  /* v = silu(v*scale[n] + shift[n])  (fused / eval-mode Conv) */
 #define SODT_EPI_DETECT 64       /* store f32 to (B, na, HW, no): Detect's view+permute */
-#define SODT_EPI_OUT_F32 128     /* C is float regardless of dtype */
+#define SODT_EPI_OUT_F32 128
+#define SODT_EPI_GELU 256        /* C = GELU(erf) of the value (after bias): fc1 when only the activation is kept */
+#define SODT_EPI_DGELU_RC 512    /* two-phase K (bf16 pipelined kernel only): the first K/2 columns of A / W recompute the
+                                  * pre-activation h = A1 W1^T (+ bias), the second K/2 give dh_act = A2 W2^T;
+                                  * C = dh_act * gelu'(h).  Backward of Linear-GELU-Linear without saving h
+                                  * (backbone_vit.py:886-904): A = [xn | dy], W = [fc1.weight | fc2.weight^T] */     /* C is float regardless of dtype */
 
 typedef struct {
   sodt_aspec a;                 /* A [M][K] as K-segments */

@@ -15,6 +15,7 @@ MAX_SEG = 9
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_RESID, EPI_GELU_DUAL, EPI_DGELU = 1, 2, 4, 8
 EPI_STATS, EPI_AFFINE_SILU, EPI_DETECT, EPI_OUT_F32 = 16, 32, 64, 128
+EPI_GELU, EPI_DGELU_RC = 256, 512
 STATS_REPL = 16      # SODT_STATS_REPL: replicas of the [2][N] f64 BatchNorm statistics buffer
 
 

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bs_kernel(const sodt_gemm_args g,
               float x[TT<T>::KPL];
               unpack<T>(raux[sm][p][c], x);
 #pragma unroll
-              for (int j = 0; j < KPL; ++j) v[j] *= dgelu_f(x[j]);
+              for (int j = 0; j < KPL; ++j) v[j] *= dgelu_t<T>(x[j]);
             }
             if (flags & SODT_EPI_RESID) {
               float x[TT<T>::KPL];
@@ -1040,6 +1040,7 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
   if ((g->flags & SODT_EPI_STATS) && !g->stats) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_AFFINE_SILU) && (!g->scale || !g->shift || ((((uintptr_t)g->scale) | ((uintptr_t)g->shift)) & 15))) return SODT_EINVAL;
   if (g->oscatter && !g->a.spatial) return SODT_EINVAL;
+  if ((g->flags & SODT_EPI_DGELU_RC) && !(dtype == SODT_BF16 && sodt_nt3_eligible(g))) return SODT_EINVAL;
   if (dtype == SODT_BF16 && (g_variant == 0 || g_variant == 3) && sodt_nt3_eligible(g)) return sodt_nt3_launch(g, (hipStream_t)st);
   // short contraction -> A-stationary kernel (row bytes a multiple of 128 so the XOR swizzle stays in-row)
   {

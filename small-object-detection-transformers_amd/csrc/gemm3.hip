@@ -223,6 +223,9 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   // the tile's last K-step, ahead of that step's DMA issues, so it lands under the MFMAs and is waited for with a
   // counted vmcnt(7); a compiler-visible load in the epilogue would wait vmcnt(0) and drain the DMA queue every tile
   constexpr bool PRE = (CF & (SODT_EPI_RESID | SODT_EPI_DGELU)) != 0;
+  // SODT_EPI_DGELU_RC: at the middle of the K range the accumulators hold the recomputed pre-activation; gelu'(h) is
+  // parked (bf16) in the same registers the prefetched operand would use and the accumulators restart for dh_act
+  constexpr bool RC = (CF & SODT_EPI_DGELU_RC) != 0;
   u32x4 pre[4][3];
   for (int s = 0; s < total; ++s) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // everything but the newest A stage has landed
@@ -270,11 +273,33 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
       mma_sw(acc[3][2][0], fw4, fa3); mma_sw(acc[3][2][1], fw5, fa3);                \
     }
     T3_KB(aRd0, wRd0)
-    if (PRE) __builtin_amdgcn_sched_barrier(0);   // keep the second half's fragment reads behind the first half's MFMAs:
+    if (PRE || RC) __builtin_amdgcn_sched_barrier(0);   // keep the second half's fragment reads behind the first half's MFMAs:
     T3_KB(aRd1, wRd1)                             //  frees ~40 VGPRs for the prefetched epilogue operand (no spills)
 #undef T3_KB
     a_slot = a_slot == 2 ? 0 : a_slot + 1;
     b_slot ^= 1;
+    if (RC && c_kt + 1 == (nk >> 1)) {
+      const int t_ = lw + c_ord * G;
+      const int n0 = (t_ % ntn) * T3_BN;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int n = n0 + wc * 96 + 32 * t + 8 * fg;
+          const u32x4 b0 = lds_rd128<0>(lbase + T3_BIASOFF + 4 * n), b1 = lds_rd128<16>(lbase + T3_BIASOFF + 4 * n);
+          T3_LGKM0();
+          float h[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { h[r] = acc[u][t][0][r]; h[4 + r] = acc[u][t][1][r]; }
+          h[0] += __uint_as_float(b0.x); h[1] += __uint_as_float(b0.y); h[2] += __uint_as_float(b0.z); h[3] += __uint_as_float(b0.w);
+          h[4] += __uint_as_float(b1.x); h[5] += __uint_as_float(b1.y); h[6] += __uint_as_float(b1.z); h[7] += __uint_as_float(b1.w);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h[j] = dgelu_t<bf16>(h[j]);
+          const uint4 pk = pack<bf16>(h);
+          pre[u][t].x = pk.x; pre[u][t].y = pk.y; pre[u][t].z = pk.z; pre[u][t].w = pk.w;
+          acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     if (++c_kt == nk) {
       // ---- epilogue of this tile straight from the accumulators: lane (fg, fi) holds, per (u, t), the 8 columns
       //      n0 + wc*96 + 32 t + 8 fg .. + 7 of row m0 + wr*64 + 16 u + fi
@@ -291,23 +316,24 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { v[r] = acc[u][t][0][r]; v[4 + r] = acc[u][t][1][r]; }
           const int n = n0 + wc * 96 + 32 * t + 8 * fg;
-          if (PRE) {
+          if (PRE || RC) {
             float x[8];
             uint4 pu; pu.x = pre[u][t].x; pu.y = pre[u][t].y; pu.z = pre[u][t].z; pu.w = pre[u][t].w;
             unpack<bf16>(pu, x);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              if (CF & SODT_EPI_DGELU) v[j] *= dgelu_f(x[j]);     // same order as epi_chunk: (bias, dgelu, resid)
+              if (RC) v[j] *= x[j];                               // parked gelu'(h)
+              else if (CF & SODT_EPI_DGELU) v[j] *= dgelu_t<bf16>(x[j]);     // same order as epi_chunk: (bias, dgelu, resid)
               else v[j] += x[j];
             }
           }
-          if (CF & SODT_EPI_BIAS) {
+          if ((CF & SODT_EPI_BIAS) && !RC) {
             const u32x4 b0 = lds_rd128<0>(lbase + T3_BIASOFF + 4 * n), b1 = lds_rd128<16>(lbase + T3_BIASOFF + 4 * n);
             T3_LGKM0();
             v[0] += __uint_as_float(b0.x); v[1] += __uint_as_float(b0.y); v[2] += __uint_as_float(b0.z); v[3] += __uint_as_float(b0.w);
             v[4] += __uint_as_float(b1.x); v[5] += __uint_as_float(b1.y); v[6] += __uint_as_float(b1.z); v[7] += __uint_as_float(b1.w);
           }
-          constexpr int CF2 = CF & ~(SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_DGELU);
+          constexpr int CF2 = CF & ~(SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_DGELU | SODT_EPI_DGELU_RC);
           if (m < g.M) epi_chunk<bf16, CF2>(g, CF2, m, n, v, hw);
           acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -697,11 +723,12 @@ int launch_tn3(const sodt_gemm_tn_args* g, hipStream_t st) {
 
 // eligibility of the pipelined kernel (bf16 only); the caller has validated pointers / alignment
 bool sodt_nt3_eligible(const sodt_gemm_args* g) {
-  const int ok_flags = SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_GELU_DUAL | SODT_EPI_DGELU;
-  if (g->flags & ~ok_flags) return false;
   switch (g->flags) {
     case 0: case SODT_EPI_BIAS: case SODT_EPI_RESID: case SODT_EPI_BIAS | SODT_EPI_RESID:
-    case SODT_EPI_BIAS | SODT_EPI_GELU_DUAL: case SODT_EPI_DGELU: break;
+    case SODT_EPI_BIAS | SODT_EPI_GELU_DUAL: case SODT_EPI_DGELU: case SODT_EPI_BIAS | SODT_EPI_GELU: break;
+    case SODT_EPI_BIAS | SODT_EPI_DGELU_RC:
+      if (g->K % (2 * T3_BK)) return false;        // both halves whole K-steps
+      break;
     default: return false;
   }
   if (g->oscatter || g->rmod > 0) return false;
@@ -723,6 +750,8 @@ int sodt_nt3_launch(const sodt_gemm_args* g, hipStream_t st) {
     case SODT_EPI_BIAS | SODT_EPI_RESID: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_RESID>(g, st);
     case SODT_EPI_BIAS | SODT_EPI_GELU_DUAL: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_GELU_DUAL>(g, st);
     case SODT_EPI_DGELU: return launch_nt3<SODT_EPI_DGELU>(g, st);
+    case SODT_EPI_BIAS | SODT_EPI_GELU: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_GELU>(g, st);
+    case SODT_EPI_BIAS | SODT_EPI_DGELU_RC: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_DGELU_RC>(g, st);
     default: return SODT_EINVAL;
   }
 }

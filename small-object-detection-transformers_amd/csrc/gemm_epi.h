@@ -39,6 +39,10 @@ __device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int rtf
       for (int j = 0; j < KPL; ++j) if (n + j < g.N) v[j] += g.bias[n + j];
     }
   }
+  if (flags & SODT_EPI_GELU) {
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) v[j] = gelu_t<T>(v[j]);
+  }
   if (flags & SODT_EPI_AFFINE_SILU) {
     float sc[KPL], sh[KPL];
     if (full) {
@@ -64,7 +68,7 @@ __device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int rtf
     if (full) { unpack<T>(*(const uint4*)ap, x); }
     else { for (int j = 0; j < KPL; ++j) x[j] = (n + j < g.N) ? to_f(ap[j]) : 0.f; }
 #pragma unroll
-    for (int j = 0; j < KPL; ++j) v[j] *= dgelu_f(x[j]);
+    for (int j = 0; j < KPL; ++j) v[j] *= dgelu_t<T>(x[j]);
   }
   if (flags & SODT_EPI_RESID) {
     const long rr = g.rmod > 0 ? (m % g.rmod) : m;
@@ -91,7 +95,7 @@ __device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int rtf
     if (flags & SODT_EPI_GELU_DUAL) {
       float a[KPL];
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) a[j] = gelu_f(v[j]);
+      for (int j = 0; j < KPL; ++j) a[j] = gelu_t<T>(v[j]);
       T* c2 = (T*)g.C2 + orow * g.ldc2 + n;
       if (full) *(uint4*)c2 = pack<T>(a);
       else for (int j = 0; j < KPL; ++j) if (n + j < g.N) c2[j] = from_f<T>(a[j]);

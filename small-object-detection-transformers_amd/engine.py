@@ -176,6 +176,18 @@ class Engine:
             add(descs_t, p, w[n], (N, K, taps), (0, 2, 1), taps * K)
             wT[n] = torch.zeros(K, taps * Np, device=dev, dtype=dt)          # [K][tap*N + n]
             add(descs_t, p, wT[n], (N, K, taps), (1, 2, 0), taps * Np)
+        # Linear MLPs on the bf16 path keep only the activation: the backward GEMM recomputes the pre-activation from
+        # [fc1.weight | fc2.weight^T] ([4C][2C]) in its first K half (SODT_EPI_DGELU_RC)
+        wcat: Dict[str, torch.Tensor] = {}
+        if dt == torch.bfloat16:
+            for n, p in self.params.items():
+                if n.endswith("mlp.fc1.weight") and p.dim() == 2 and p.shape[0] == 4 * p.shape[1]:
+                    Cc = p.shape[1]
+                    p2 = self.params[n.replace("fc1", "fc2")]
+                    wc = torch.zeros(4 * Cc, 2 * Cc, device=dev, dtype=dt)
+                    add(descs_t, p, wc, (4 * Cc, Cc, 1), (0, 2, 1), 2 * Cc)
+                    add(descs_t, p2, wc[:, Cc:], (Cc, 4 * Cc, 1), (1, 2, 0), 2 * Cc)
+                    wcat[n] = wc
         # f32 side: transposed relative-position tables, packed front-end parameters
         bias_t: Dict[str, torch.Tensor] = {}
         for n, p in self.params.items():
@@ -194,7 +206,7 @@ class Engine:
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             mx = max(d.d0 * d.d1 * d.d2 for d in descs)
             return host.to(dev), len(descs), mx
-        P = dict(w=w, wT=wT, bias_t=bias_t, fe=fe, tab_t=table(descs_t), tab_f=table(descs_f), dt=dt,
+        P = dict(w=w, wT=wT, wcat=wcat, bias_t=bias_t, fe=fe, tab_t=table(descs_t), tab_f=table(descs_f), dt=dt,
                  ones={}, keep=(descs_t, descs_f))
         self.prep[dt] = P
         return P
@@ -363,9 +375,13 @@ class Engine:
         ops.layernorm_fwd(xm, p[pre + "norm2.weight"], p[pre + "norm2.bias"], xn2, st2, M, Cc)
         xo = plan.buf(tag + ".xo", (M, Cc))
         if blk.mlp.linear:
-            hp = plan.buf(tag + ".hp", (M, 4 * Cc))
             ha = plan.buf(tag + ".ha", (M, 4 * Cc))
-            ops.gemm_nt([SegSpec(xn2)], w[pre + "mlp.fc1.weight"], hp, M, 4 * Cc, Cc, bias=p[pre + "mlp.fc1.bias"], gelu_out=ha)
+            if ops.mlp_recompute_ok(M, Cc, ha.dtype) and (pre + "mlp.fc1.weight") in P["wcat"]:
+                # only GELU(h) is written; backward recomputes h inside the dh GEMM
+                ops.gemm_nt([SegSpec(xn2)], w[pre + "mlp.fc1.weight"], ha, M, 4 * Cc, Cc, bias=p[pre + "mlp.fc1.bias"], gelu_only=True)
+            else:
+                hp = plan.buf(tag + ".hp", (M, 4 * Cc))
+                ops.gemm_nt([SegSpec(xn2)], w[pre + "mlp.fc1.weight"], hp, M, 4 * Cc, Cc, bias=p[pre + "mlp.fc1.bias"], gelu_out=ha)
             ops.gemm_nt([SegSpec(ha)], w[pre + "mlp.fc2.weight"], xo, M, Cc, 4 * Cc, bias=p[pre + "mlp.fc2.bias"], resid=xm)
         else:
             u = plan.buf(tag + ".u", (M, Cc))
@@ -392,10 +408,14 @@ class Engine:
         dxn = plan.buf(f"g.dxn.{Cc}", (M, Cc))
         dxm = plan.buf(f"g.dxm.{Cc}", (M, Cc))
         if blk.mlp.linear:
-            hp, ha = b[tag + ".hp"], b[tag + ".ha"]
+            ha = b[tag + ".ha"]
             dh = plan.buf(f"g.dh.{Cc}", (M, 4 * Cc))
             ops.gemm_tn(dY, [SegSpec(ha)], g[pre + "mlp.fc2.weight"], M, Cc, 4 * Cc, dbias=g[pre + "mlp.fc2.bias"])
-            ops.gemm_nt([SegSpec(dY)], wT[pre + "mlp.fc2.weight"], dh, M, 4 * Cc, Cc, dgelu_aux=hp)
+            if (tag + ".hp") in b:
+                ops.gemm_nt([SegSpec(dY)], wT[pre + "mlp.fc2.weight"], dh, M, 4 * Cc, Cc, dgelu_aux=b[tag + ".hp"])
+            else:       # dh = (dY fc2.weight) * gelu'(xn2 fc1.weight^T + b1): pre-activation recomputed in the first K half
+                ops.gemm_nt([SegSpec(xn2), SegSpec(dY)], P["wcat"][pre + "mlp.fc1.weight"], dh, M, 4 * Cc, 2 * Cc,
+                            bias=p[pre + "mlp.fc1.bias"], dgelu_rc=True)
             ops.gemm_tn(dh, [SegSpec(xn2)], g[pre + "mlp.fc1.weight"], M, 4 * Cc, Cc, dbias=g[pre + "mlp.fc1.bias"])
             ops.gemm_nt([SegSpec(dh)], wT[pre + "mlp.fc1.weight"], dxn, M, Cc, 4 * Cc)
         else:

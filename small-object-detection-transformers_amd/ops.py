@@ -123,7 +123,8 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
             gelu_out: Optional[torch.Tensor] = None, dgelu_aux: Optional[torch.Tensor] = None,
             stats: Optional[torch.Tensor] = None, affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
             out_f32: bool = False, detect: Optional[Tuple[int, int, int]] = None,
-            oscatter: Optional[Tuple[int, int, int, int, int]] = None, w_off: int = 0, debug_flags: int = 0) -> None:
+            oscatter: Optional[Tuple[int, int, int, int, int]] = None, w_off: int = 0, debug_flags: int = 0,
+            gelu_only: bool = False, dgelu_rc: bool = False) -> None:
     """out[M][N] = epilogue(concat_k(segs) @ W[N][K]^T); see SODT_EPI_* in include/sodt_hip.h."""
     g = L.GemmArgs()
     _fill_aspec(g.a, segs, spatial)
@@ -164,8 +165,18 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
     if oscatter is not None:
         g.oscatter = 1
         g.omul, g.ody, g.odx, g.OH, g.OW = oscatter
+    if gelu_only:
+        flags |= L.EPI_GELU
+    if dgelu_rc:
+        flags |= L.EPI_DGELU_RC
     g.M, g.N, g.K, g.flags = M, N, K, flags | debug_flags
     _launch("sodt_gemm_nt", C.byref(g), dt_code(W))
+
+
+def mlp_recompute_ok(M: int, Cc: int, dtype: torch.dtype) -> bool:
+    """Linear-GELU-Linear with only the activation saved (SODT_EPI_GELU forward, SODT_EPI_DGELU_RC backward): needs the
+    pipelined bf16 kernel for N = 4C, K = 2C (csrc/gemm3.hip: N % 192 == 0, K-halves whole 64-wide steps, bias in LDS)."""
+    return dtype == torch.bfloat16 and M >= 256 and (4 * Cc) % 192 == 0 and Cc % 64 == 0 and 4 * Cc <= 3072
 
 
 def tn_splits(M: int, N: int, K: int, bf16: bool = False) -> int:

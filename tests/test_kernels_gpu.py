@@ -284,6 +284,34 @@ def test_gemm_tn_conv_weight_grad(ops, dev, dt, variant):
     close(dW, w2.grad, dt, what="conv2x2 dW (torch layout)")
 
 
+def test_gemm_nt_gelu_only_and_dgelu_recompute(ops, dev):
+    """Linear-GELU-Linear with only the activation kept (bf16 pipelined kernel): SODT_EPI_GELU writes GELU(xn W1^T + b1);
+    SODT_EPI_DGELU_RC computes dh = (dy W2) * gelu'(xn W1^T + b1) from A = [xn | dy], W = [W1 | W2^T], recomputing the
+    pre-activation in the first K half."""
+    dt = torch.bfloat16
+    ops.gemm_set_variant(0)
+    for (M, Cc) in [(3000, 192), (256 * 9 + 7, 384), (1024, 768)]:
+        xn = rnd((M, Cc), dev, dt, 1)
+        dy = rnd((M, Cc), dev, dt, 2)
+        W1 = rnd((4 * Cc, Cc), dev, dt, 3, 1 / math.sqrt(Cc))
+        W2 = rnd((Cc, 4 * Cc), dev, dt, 4, 1 / math.sqrt(4 * Cc))
+        b1 = rnd((4 * Cc,), dev, torch.float32, 5)
+        assert ops.mlp_recompute_ok(M, Cc, dt)
+        act = torch.zeros(M, 4 * Cc, device=dev, dtype=dt)
+        ops.gemm_nt([ops.SegSpec(xn)], W1, act, M, 4 * Cc, Cc, bias=b1, gelu_only=True)
+        h = (xn.float() @ W1.float().t() + b1).double().requires_grad_(True)
+        close(act, F.gelu(h), dt, what=f"gelu only C={Cc}")
+        F.gelu(h).sum().backward()
+        Wcat = torch.cat([W1, W2.t().contiguous()], 1).contiguous()
+        dh = torch.zeros(M, 4 * Cc, device=dev, dtype=dt)
+        ops.gemm_nt([ops.SegSpec(xn), ops.SegSpec(dy)], Wcat, dh, M, 4 * Cc, 2 * Cc, bias=b1, dgelu_rc=True)
+        close(dh, (dy.float() @ W2.float()).double() * h.grad, dt, what=f"dgelu recompute C={Cc}")
+    # a shape the pipelined kernel does not take must be refused, not silently mis-computed
+    xn = rnd((512, 128), dev, dt, 1); W = rnd((512, 256), dev, dt, 2); out = torch.zeros(512, 512, device=dev, dtype=dt)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt([ops.SegSpec(xn), ops.SegSpec(xn)], W, out, 512, 512, 256, bias=torch.zeros(512, device=dev), dgelu_rc=True)
+
+
 def test_gemm_tn_pipelined_bf16(ops, dev):
     """The LDS-DMA pipelined bf16 weight-gradient kernel (csrc/gemm3.hip): both tile orientations, N / K tails,
     ragged M slices, dbias through the ones-MFMA, conv taps with the torch-layout K permutation."""

@@ -9,8 +9,8 @@ rows = list(csv.DictReader(open(st)))
 line = [l for l in open(f"{src}/stats.log") if l.startswith('{"metric"')][0]
 bench = json.loads(line)
 steps = bench["steps"] + max(bench["warmup"], 2)
-KEYS = ("gemm_nt3_kernelILi5E", "gemm_nt3_kernel<5>")
-KEY = "gemm_nt3_kernel<5>"       # pipelined bf16 NT kernel, flags BIAS|GELU_DUAL: every linear fc1; the stage-1 launches
+KEYS = ("gemm_nt3_kernelILi257E", "gemm_nt3_kernel<257>")
+KEY = "gemm_nt3_kernel<257>"       # pipelined bf16 NT kernel, flags BIAS|GELU: every linear fc1; the stage-1 launches
                                    # (M=524288, N=768, K=192) are the longest of them, selected by duration below
 def dispatches(path, name=None):
     """(duration_ns, counter_value) of every dispatch of KEY in a rocprofv3 CSV (kernel trace or counter collection)."""
@@ -42,5 +42,5 @@ with open(f"profiles/{tag}_summary.md", "w") as f:
     for r in rows[:22]:
         f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6/steps:.2f} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |\n")
     f.write(f"\nRoofline kernel (stage-1 fc1 = the longest launches of `{KEY}`): rocprof kernel-trace average {avg_ns/1e3:.1f} us; HBM traffic per launch "
-            f"{traffic['hbm_bytes_per_launch']/1e6:.0f} MB (FETCH_SIZE {fetch_kb:.0f} KB x2 + WRITE_SIZE {write_kb:.0f} KB) vs 1811 MB algorithmic.\n")
+            f"{traffic['hbm_bytes_per_launch']/1e6:.0f} MB (FETCH_SIZE {fetch_kb:.0f} KB x2 + WRITE_SIZE {write_kb:.0f} KB) vs 1007 MB algorithmic.\n")
 print(json.dumps(traffic)[:300])
