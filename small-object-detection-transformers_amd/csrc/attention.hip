@@ -1125,6 +1125,272 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
 #undef B2_STORE_ONE
 }
 
+// ---------------------------------------------------------------------------------
+// backward, windows of more than 64 tokens (16x16, 32x32, 64x64), register-resident P / dS.
+// One workgroup = NW waves = NW heads of one (window, 64-key tile); the 64-query tiles of the window are walked with
+// the kv tile's dK / dV in registers.  Same operand scheme as attn_bwd_fast2_kernel: P and dS leave the S / dP
+// accumulators as (strip pairs of) A operands for dV += P^T dO and dK += dS^T Q; dS goes through a 3 KiB per-wave
+// [key][16 q] patch one strip at a time for dQ = dS K, whose finished strips are added to the f32 dQ accumulator
+// straight from the accumulators.  No P^T / dS^T tiles and no full bias-gradient table in LDS: 44 KiB per
+// workgroup at hd 64 (was 59 + 16), three workgroups per CU.  delta = rowsum(dO o O) comes from attn_delta_kernel.
+// ---------------------------------------------------------------------------------
+template <typename T, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_mt_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
+                                                             const T* __restrict__ d_out, const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                             float* __restrict__ dbias_t, float* __restrict__ dq_acc,
+                                                             const AttnGeo g, int nwin_total) {
+  using L = Lay<T, HD>;
+  constexpr int E = L::E, KPL = L::KPL, NT = NW * 64, CPR = NW * L::DCH, MK = TT<T>::MMA_K;
+  constexpr int SPK = MK / 16;
+  constexpr int DSROW = 16 * E + 16;
+  constexpr int LTMAX = 225;
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE], sK[NW * L::QTILE], sV[NW * L::QTILE],
+      sDO[NW * L::QTILE];
+  __shared__ __attribute__((aligned(16))) unsigned char sDS[NW * 64 * DSROW];
+  __shared__ float sDB[NW][LTMAX + 3];
+  __shared__ float sBias[NW][LTMAX + 3];
+  __shared__ float sLse[NW][64], sDelta[NW][64];
+  __shared__ int sTokQ[64], sTokK[64];
+  __shared__ short sGeoQ[64][4], sGeoK[64][4];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int hg = blockIdx.y, head = hg * NW + w;
+  const int C3 = 3 * g.C, L2 = 2 * g.ws - 1;
+  const int R = g.ws >= 64 ? 1 : 64 / g.ws;
+  const int LT = (2 * R - 1) * L2;
+  const float scale = rsqrtf((float)HD), scale2 = scale * SODT_LOG2E;
+  const float* bt = bias_t + (long)head * L2 * L2;
+  unsigned char* myQ = sQ + w * L::QTILE; unsigned char* myK = sK + w * L::QTILE;
+  unsigned char* myV = sV + w * L::QTILE; unsigned char* myDO = sDO + w * L::QTILE;
+  unsigned char* myDS = sDS + w * 64 * DSROW;
+  for (int i = tid; i < NW * (LTMAX + 3); i += NT) (&sDB[0][0])[i] = 0.f;
+
+  // the next query tile (Q, dO rows + lse, delta) is fetched into registers under the current pair's MFMAs; named scalars:
+  // hipcc leaves uint4 arrays used like this in scratch
+  constexpr int NPF = 64 * CPR / NT;            // chunks per thread and tensor (= DCH)
+  constexpr bool PF = NPF <= 8;                 // f32 at hd 64 (16 chunks) loads each tile where it is used instead
+  uint4 pq0, pq1, pq2, pq3, pq4, pq5, pq6, pq7, pd0, pd1, pd2, pd3, pd4, pd5, pd6, pd7;
+  float plse = 0.f, pdel = 0.f;
+#define MT_ISSUE_ONE(i, B_, WY_, WX_, QT_)                                              \
+  if constexpr (PF && NPF > i) {                                                        \
+    const int idx = tid + i * NT;                                                       \
+    const int r = idx / CPR, cc = idx - r * CPR;                                        \
+    int row, rid, iy, ix;                                                               \
+    win_token(g, B_, WY_, WX_, (QT_) * 64 + r, row, rid, iy, ix);                       \
+    pq##i = *(const uint4*)(qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL);          \
+    pd##i = *(const uint4*)(d_out + (long)row * g.C + (hg * NW) * HD + cc * KPL);       \
+  }
+#define MT_ISSUE(B_, WY_, WX_, QT_) {                                                   \
+    MT_ISSUE_ONE(0, B_, WY_, WX_, QT_) MT_ISSUE_ONE(1, B_, WY_, WX_, QT_) MT_ISSUE_ONE(2, B_, WY_, WX_, QT_) \
+    MT_ISSUE_ONE(3, B_, WY_, WX_, QT_) MT_ISSUE_ONE(4, B_, WY_, WX_, QT_) MT_ISSUE_ONE(5, B_, WY_, WX_, QT_) \
+    MT_ISSUE_ONE(6, B_, WY_, WX_, QT_) MT_ISSUE_ONE(7, B_, WY_, WX_, QT_)               \
+    int row2, rid2, iy2, ix2;                                                           \
+    win_token(g, B_, WY_, WX_, (QT_) * 64 + lane, row2, rid2, iy2, ix2);                \
+    plse = lse[(long)row2 * g.heads + head]; pdel = delta[(long)row2 * g.heads + head]; \
+  }
+#define MT_STORE_ONE(i)                                                                 \
+  if constexpr (PF && NPF > i) {                                                              \
+    const int idx = tid + i * NT;                                                       \
+    const int r = idx / CPR, cc = idx - r * CPR;                                        \
+    const int h = cc / L::DCH, dc = cc - h * L::DCH;                                    \
+    const int off = (h * 64 + r) * L::QROW + dc * 16;                                   \
+    *(uint4*)(sQ + off) = pq##i; *(uint4*)(sDO + off) = pd##i;                          \
+  }
+  const int nitems = nwin_total * g.nqt;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    int t = item;
+    const int kt = t % g.nqt; t /= g.nqt;
+    const int wx = t % g.nwx; t /= g.nwx;
+    const int wy = t % g.nwy; const int b = t / g.nwy;
+    const bool msk = g.shift > 0 && (wy == g.nwy - 1 || wx == g.nwx - 1);
+    __syncthreads();
+    if (tid < 64) {
+      int row, rid, iy, ix;
+      win_token(g, b, wy, wx, kt * 64 + tid, row, rid, iy, ix);
+      sTokK[tid] = row; sGeoK[tid][0] = (short)iy; sGeoK[tid][1] = (short)ix; sGeoK[tid][2] = (short)rid;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CPR; idx += NT) {
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int h = cc / L::DCH, dc = cc - h * L::DCH;
+      const T* src = qkv + (long)sTokK[r] * C3 + (hg * NW) * HD + cc * KPL;
+      *(uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(src + g.C);
+      *(uint4*)(sV + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(src + 2 * g.C);
+    }
+    f32x4 dk[4][HD / 16], dv[4][HD / 16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int d = 0; d < HD / 16; ++d) { dk[i][d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    MT_ISSUE(b, wy, wx, 0)
+
+    for (int qt = 0; qt < g.nqt; ++qt) {
+      __syncthreads();
+      if (tid < 64) {
+        int row, rid, iy, ix;
+        win_token(g, b, wy, wx, qt * 64 + tid, row, rid, iy, ix);
+        sTokQ[tid] = row; sGeoQ[tid][0] = (short)iy; sGeoQ[tid][1] = (short)ix; sGeoQ[tid][2] = (short)rid;
+      }
+      __syncthreads();
+      const int dyoff = (qt - kt) * R;
+      for (int i = lane; i < LT; i += 64) {
+        const int a = i / L2, c = i - a * L2;
+        const int gy = a - (R - 1) + dyoff + g.ws - 1;
+        sBias[w][i] = (gy >= 0 && gy < L2) ? bt[gy * L2 + c] * SODT_LOG2E : 0.f;
+      }
+      if constexpr (!PF) {
+        for (int idx = tid; idx < 64 * CPR; idx += NT) {
+          const int r = idx / CPR, cc = idx - r * CPR;
+          const int h = cc / L::DCH, dc = cc - h * L::DCH;
+          *(uint4*)(sQ + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(qkv + (long)sTokQ[r] * C3 + (hg * NW) * HD + cc * KPL);
+          *(uint4*)(sDO + (h * 64 + r) * L::QROW + dc * 16) = *(const uint4*)(d_out + (long)sTokQ[r] * g.C + (hg * NW) * HD + cc * KPL);
+        }
+      }
+      sLse[w][lane] = plse * SODT_LOG2E;
+      sDelta[w][lane] = pdel;
+      MT_STORE_ONE(0) MT_STORE_ONE(1) MT_STORE_ONE(2) MT_STORE_ONE(3) MT_STORE_ONE(4) MT_STORE_ONE(5) MT_STORE_ONE(6) MT_STORE_ONE(7)
+      __syncthreads();
+      {   // unconditional (clamped) so that the prefetch registers stay registers
+        const int nq_ = qt + 1 < g.nqt ? qt + 1 : qt;
+        MT_ISSUE(b, wy, wx, nq_)
+      }
+
+      int kiy[4], kix[4], krid[4];
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) {
+        kiy[ns] = sGeoK[ns * 16 + fr][0]; kix[ns] = sGeoK[ns * 16 + fr][1]; krid[ns] = sGeoK[ns * 16 + fr][2];
+      }
+      f32x4 dbacc[4][4];
+#pragma unroll
+      for (int kbq = 0; kbq < 4 / SPK; ++kbq) {
+        uint4 Ap[4], Ads[4];
+#pragma unroll
+        for (int hh = 0; hh < SPK; ++hh) {
+          const int ms = kbq * SPK + hh;
+          f32x4 s[4], dp[4];
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns) { s[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+          for (int kb = 0; kb < L::KBQ; ++kb) {
+            const uint4 fq = frag<T>(myQ, L::QROW, ms * 16, kb, HD, lane);
+            const uint4 fo = frag<T>(myDO, L::QROW, ms * 16, kb, HD, lane);
+#pragma unroll
+            for (int ns = 0; ns < 4; ++ns) {
+              const uint4 fk = frag<T>(myK, L::QROW, ns * 16, kb, HD, lane);
+              const uint4 fv = frag<T>(myV, L::QROW, ns * 16, kb, HD, lane);
+              mma16<T>(s[ns], fq, fk);
+              mma16<T>(dp[ns], fo, fv);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qn = ms * 16 + fg * 4 + r;
+            const float lq = sLse[w][qn], dl = sDelta[w][qn];
+            const int qiy = sGeoQ[qn][0], qix = sGeoQ[qn][1], qrid = sGeoQ[qn][2];
+#pragma unroll
+            for (int ns = 0; ns < 4; ++ns) {
+              float v = fmaf(s[ns][r], scale2, sBias[w][(qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1)]);
+              if (msk && qrid != krid[ns]) v += -100.0f * SODT_LOG2E;
+              const float p = fast_exp2(v - lq);
+              s[ns][r] = p;
+              const float ds = p * (dp[ns][r] - dl);
+              dp[ns][r] = ds;
+            }
+          }
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns) {
+            dbacc[ms][ns] = dp[ns];
+            if constexpr (std::is_same<T, bf16>::value) {
+              const uint32_t p01 = pack2bf(s[ns][0], s[ns][1]), p23 = pack2bf(s[ns][2], s[ns][3]);
+              const uint32_t d01 = pack2bf(dp[ns][0], dp[ns][1]), d23 = pack2bf(dp[ns][2], dp[ns][3]);
+              if (hh == 0) { Ap[ns].x = p01; Ap[ns].y = p23; Ads[ns].x = d01; Ads[ns].y = d23; }
+              else { Ap[ns].z = p01; Ap[ns].w = p23; Ads[ns].z = d01; Ads[ns].w = d23; }
+              *(uint2*)(myDS + (ns * 16 + fr) * DSROW + 8 * fg) = make_uint2(d01, d23);
+            } else {
+              Ap[ns] = make_uint4(__float_as_uint(s[ns][0]), __float_as_uint(s[ns][1]), __float_as_uint(s[ns][2]), __float_as_uint(s[ns][3]));
+              Ads[ns] = make_uint4(__float_as_uint(dp[ns][0]), __float_as_uint(dp[ns][1]), __float_as_uint(dp[ns][2]), __float_as_uint(dp[ns][3]));
+              *(float4*)(myDS + (ns * 16 + fr) * DSROW + 16 * fg) = make_float4(dp[ns][0], dp[ns][1], dp[ns][2], dp[ns][3]);
+            }
+          }
+          // dQ strip ms = dS K, added to the f32 accumulator of the window straight from the MFMA accumulators
+          f32x4 dq[HD / 16];
+#pragma unroll
+          for (int d = 0; d < HD / 16; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kb = 0; kb < L::KBT; ++kb) {
+            const uint4 fst = fragT<T>(myDS, DSROW, kb * MK, 0, lane);
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d) mma16<T>(dq[d], fst, fragT<T>(myK, L::QROW, kb * MK, d * 16, lane));
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long tq = sTokQ[ms * 16 + fg * 4 + r];
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d)
+              atomicAdd(dq_acc + tq * g.C + head * HD + d * 16 + fr, dq[d][r] * scale);
+          }
+        }
+        uint4 fdo[HD / 16], fqq[HD / 16];
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) {
+          fdo[d] = fragTp<T>(myDO, L::QROW, kbq, d * 16, lane);
+          fqq[d] = fragTp<T>(myQ, L::QROW, kbq, d * 16, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int d = 0; d < HD / 16; ++d) {
+            mma16<T>(dv[ks][d], Ap[ks], fdo[d]);
+            mma16<T>(dk[ks][d], Ads[ks], fqq[d]);
+          }
+      }
+      // bias gradient of this (q tile, kv tile) pair: registers -> per-wave LDS table -> global atomics
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qn = ms * 16 + fg * 4 + r;
+          const int qiy = sGeoQ[qn][0], qix = sGeoQ[qn][1];
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns)
+            atomicAdd(&sDB[w][(qiy - kiy[ns] - dyoff + R - 1) * L2 + (qix - kix[ns] + g.ws - 1)], dbacc[ms][ns][r]);
+        }
+      __syncthreads();
+      for (int i = lane; i < LT; i += 64) {
+        const int a = i / L2, c = i - a * L2;
+        const int gy = a - (R - 1) + dyoff + g.ws - 1;
+        const float v = sDB[w][i];
+        if (gy >= 0 && gy < L2 && v != 0.f) atomicAdd(dbias_t + (long)head * L2 * L2 + gy * L2 + c, v);
+        sDB[w][i] = 0.f;
+      }
+    }
+    // ---- dK, dV of this kv tile -> staged through this head's K / V tiles -> dqkv[:, C:2C], [:, 2C:3C]
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) {
+          st_elem<T>(myK + (ks * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dk[ks][d][r] * scale);
+          st_elem<T>(myV + (ks * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dv[ks][d][r]);
+        }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CPR; idx += NT) {
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int h = cc / L::DCH, dc = cc - h * L::DCH;
+      T* dst = dqkv + (long)sTokK[r] * C3 + (hg * NW) * HD + cc * KPL;
+      *(uint4*)(dst + g.C) = *(const uint4*)(sK + (h * 64 + r) * L::QROW + dc * 16);
+      *(uint4*)(dst + 2 * g.C) = *(const uint4*)(sV + (h * 64 + r) * L::QROW + dc * 16);
+    }
+  }
+}
+#undef MT_ISSUE_ONE
+#undef MT_ISSUE
+#undef MT_STORE_ONE
+
 bool make_geo(AttnGeo& g, int B, int H, int W, int C, int heads, int ws, int shift) {
   if (B <= 0 || H <= 0 || W <= 0 || ws <= 0 || (H % ws) || (W % ws) || heads <= 0 || (C % heads)) return false;
   if ((ws * ws) % 64) return false;
@@ -1178,6 +1444,12 @@ int launch_bwd(const void* qkv, const float* bias_t, const void* out, const void
     hipLaunchKernelGGL((attn_bwd_kernel<T, HD, NW, PFOK>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
                        (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin, 0);
   } else {
+    if (g.nqt > 1) {
+      hipLaunchKernelGGL((attn_bwd_mt_kernel<T, HD, NW>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
+                         (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin);
+      hipLaunchKernelGGL((attn_dq_finish_kernel<T>), dim3(1024), dim3(256), 0, st, dq_acc, (T*)dqkv, M, g.C);
+      return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+    }
     // multi-tile windows: keep the whole (2ws-1)^2 bias-gradient table of each head in LDS when it fits
     using L = Lay<T, HD>;
     const int L2 = 2 * g.ws - 1;
