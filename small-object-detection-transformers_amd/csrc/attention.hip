@@ -446,6 +446,199 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
 }
 
 // ---------------------------------------------------------------------------------
+// forward, windows of more than 64 tokens.  One workgroup = four waves = four 64-query tiles of ONE (window, head):
+// the K / V tiles are staged once per workgroup and shared (a quarter of the L2 traffic of one tile per workgroup), the
+// next K / V tile is prefetched into registers.  Scores are computed transposed (S^T = K Q^T: keys on the accumulator
+// rows, a query per lane column), so the online softmax of a query is in-lane work plus two cross-group shuffles and
+// P leaves the accumulators directly as the A operand of O += P V (strip pairs for bf16; V read with the transposing
+// LDS load in the same order).  No P tile in LDS.
+// ---------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ uint4 fragTp_fwd(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane);
+template <> __device__ __forceinline__ uint4 fragTp_fwd<bf16>(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned char* a = tile + (32 * kbq + 4 * g + q) * rowbytes + (col0 + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  union { s16x4 v; uint2 u; } lo, hi;
+  lo.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  hi.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 16 * rowbytes));
+  return make_uint4(lo.u.x, lo.u.y, hi.u.x, hi.u.y);
+}
+template <> __device__ __forceinline__ uint4 fragTp_fwd<float>(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane) {
+  return fragT<float>(tile, rowbytes, 16 * kbq, col0, lane);
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_fwd_mt_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
+                                                         T* __restrict__ out, float* __restrict__ lse, const AttnGeo g) {
+  using L = Lay<T, HD>;
+  constexpr int E = L::E, KPL = L::KPL, MK = TT<T>::MMA_K, SPK = MK / 16;
+  constexpr int NPF = 64 * L::DCH / 256;         // K (and V) chunks per thread per tile
+  static_assert(NPF >= 1 && NPF <= 4, "prefetch slots");
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[4 * L::QTILE];     // one query tile per wave
+  __shared__ __attribute__((aligned(16))) unsigned char sK[L::QTILE], sV[L::QTILE];
+  __shared__ int sTokQ[4][64], sTokK[64];
+  __shared__ short sGeoQ[4][64][4], sGeoK[64][4];
+  __shared__ float sBias[4][228];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  int bid = blockIdx.x;
+  const int head = bid % g.heads; bid /= g.heads;
+  const int qg = bid % (g.nqt / 4); bid /= (g.nqt / 4);
+  const int wx = bid % g.nwx; bid /= g.nwx;
+  const int wy = bid % g.nwy; const int b = bid / g.nwy;
+  const int qt = qg * 4 + w;
+  const int C3 = 3 * g.C, L2 = 2 * g.ws - 1;
+  const int R = g.ws >= 64 ? 1 : 64 / g.ws;
+  const int LT = (2 * R - 1) * L2;
+  const float scale2 = rsqrtf((float)HD) * SODT_LOG2E;
+  const float* bt = bias_t + (long)head * L2 * L2;
+  const bool msk = g.shift > 0 && (wy == g.nwy - 1 || wx == g.nwx - 1);
+  unsigned char* myQ = sQ + w * L::QTILE;
+
+  {
+    int row, rid, iy, ix;
+    win_token(g, b, wy, wx, qt * 64 + lane, row, rid, iy, ix);
+    sTokQ[w][lane] = row; sGeoQ[w][lane][0] = (short)iy; sGeoQ[w][lane][1] = (short)ix; sGeoQ[w][lane][2] = (short)rid;
+  }
+  __syncthreads();
+  for (int idx = lane; idx < 64 * L::DCH; idx += 64) {           // this wave's own query tile
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;
+    *(uint4*)(myQ + r * L::QROW + dc * 16) = *(const uint4*)(qkv + (long)sTokQ[w][r] * C3 + head * HD + dc * KPL);
+  }
+  // this lane's query column of every strip: geometry for bias / mask
+  int qiy[4], qix[4], qrid[4];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) {
+    qiy[ms] = sGeoQ[w][ms * 16 + fr][0]; qix[ms] = sGeoQ[w][ms * 16 + fr][1]; qrid[ms] = sGeoQ[w][ms * 16 + fr][2];
+  }
+  float m_run[4], l_run[4];
+  f32x4 o[4][HD / 16];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) {
+    m_run[ms] = -1e30f; l_run[ms] = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD / 16; ++d) o[ms][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  uint4 pk0, pk1, pk2, pk3, pv0, pv1, pv2, pv3;
+#define FM_ISSUE_ONE(i, KT_)                                                            \
+  if constexpr (NPF > i) {                                                              \
+    const int idx = tid + i * 256;                                                      \
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;                                  \
+    int row, rid, iy, ix;                                                               \
+    win_token(g, b, wy, wx, (KT_) * 64 + r, row, rid, iy, ix);                          \
+    const T* src = qkv + (long)row * C3 + head * HD + dc * KPL;                         \
+    pk##i = *(const uint4*)(src + g.C); pv##i = *(const uint4*)(src + 2 * g.C);         \
+  }
+#define FM_ISSUE(KT_) { FM_ISSUE_ONE(0, KT_) FM_ISSUE_ONE(1, KT_) FM_ISSUE_ONE(2, KT_) FM_ISSUE_ONE(3, KT_) }
+#define FM_STORE_ONE(i)                                                                 \
+  if constexpr (NPF > i) {                                                              \
+    const int idx = tid + i * 256;                                                      \
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;                                  \
+    *(uint4*)(sK + r * L::QROW + dc * 16) = pk##i; *(uint4*)(sV + r * L::QROW + dc * 16) = pv##i; \
+  }
+  FM_ISSUE(0)
+
+  for (int kt = 0; kt < g.nqt; ++kt) {
+    __syncthreads();                                   // every wave is done with the previous K / V tile
+    if (tid < 64) {
+      int row, rid, iy, ix;
+      win_token(g, b, wy, wx, kt * 64 + tid, row, rid, iy, ix);
+      sGeoK[tid][0] = (short)iy; sGeoK[tid][1] = (short)ix; sGeoK[tid][2] = (short)rid;
+    }
+    FM_STORE_ONE(0) FM_STORE_ONE(1) FM_STORE_ONE(2) FM_STORE_ONE(3)
+    const int dyoff = (qt - kt) * R;
+    for (int i = lane; i < LT; i += 64) {
+      const int a = i / L2, c = i - a * L2;
+      const int gy = a - (R - 1) + dyoff + g.ws - 1;
+      sBias[w][i] = (gy >= 0 && gy < L2) ? bt[gy * L2 + c] * SODT_LOG2E : 0.f;
+    }
+    __syncthreads();
+    { const int nk_ = kt + 1 < g.nqt ? kt + 1 : kt; FM_ISSUE(nk_) }
+
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      // S^T strip: keys on rows (4 fg + r of key strip ks), this lane's query = ms*16 + fr
+      f32x4 s[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < L::KBQ; ++kb) {
+        const uint4 fq = frag<T>(myQ, L::QROW, ms * 16, kb, HD, lane);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) mma16<T>(s[ks], frag<T>(sK, L::QROW, ks * 16, kb, HD, lane), fq);
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kn = ks * 16 + fg * 4 + r;
+          const int kiy = sGeoK[kn][0], kix = sGeoK[kn][1];
+          float v = fmaf(s[ks][r], scale2, sBias[w][(qiy[ms] - kiy - dyoff + R - 1) * L2 + (qix[ms] - kix + g.ws - 1)]);
+          if (msk && qrid[ms] != (int)sGeoK[kn][2]) v += -100.0f * SODT_LOG2E;
+          s[ks][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mnew = fmaxf(m_run[ms], mx);
+      const float alpha = fast_exp2(m_run[ms] - mnew);
+      float sum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float p = fast_exp2(s[ks][r] - mnew); s[ks][r] = p; sum += p; }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      l_run[ms] = l_run[ms] * alpha + sum;
+      m_run[ms] = mnew;
+      // rescale O rows (row 4 fg + r of strip ms <-> query column 4 fg + r of this strip, held by lane 4 fg + r)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ar = __shfl(alpha, 4 * fg + r);
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) o[ms][d][r] *= ar;
+      }
+      // O[ms] += P V: P strips straight from the accumulators (A operand: row = query fr, k-slots = keys)
+#pragma unroll
+      for (int kbq = 0; kbq < 4 / SPK; ++kbq) {
+        uint4 ap;
+        if constexpr (std::is_same<T, bf16>::value) {
+          ap = make_uint4(pack2bf(s[2 * kbq][0], s[2 * kbq][1]), pack2bf(s[2 * kbq][2], s[2 * kbq][3]),
+                          pack2bf(s[2 * kbq + 1][0], s[2 * kbq + 1][1]), pack2bf(s[2 * kbq + 1][2], s[2 * kbq + 1][3]));
+        } else {
+          ap = make_uint4(__float_as_uint(s[kbq][0]), __float_as_uint(s[kbq][1]), __float_as_uint(s[kbq][2]), __float_as_uint(s[kbq][3]));
+        }
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) mma16<T>(o[ms][d], ap, fragTp_fwd<T>(sV, L::QROW, kbq, d * 16, lane));
+      }
+    }
+  }
+  // ---- normalise, lse, stage O through this wave's query tile, coalesced store
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) {
+    const float inv = __builtin_amdgcn_rcpf(l_run[ms]);
+    if (fg == 0 && lse) lse[(long)sTokQ[w][ms * 16 + fr] * g.heads + head] = m_run[ms] * (1.0f / SODT_LOG2E) + __logf(l_run[ms]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ir = __shfl(inv, 4 * fg + r);
+#pragma unroll
+      for (int d = 0; d < HD / 16; ++d)
+        st_elem<T>(myQ + (ms * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, o[ms][d][r] * ir);
+    }
+  }
+  for (int idx = lane; idx < 64 * L::DCH; idx += 64) {
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;
+    *(uint4*)(out + (long)sTokQ[w][r] * g.C + head * HD + dc * KPL) = *(const uint4*)(myQ + r * L::QROW + dc * 16);
+  }
+#undef FM_ISSUE_ONE
+#undef FM_ISSUE
+#undef FM_STORE_ONE
+}
+
+// ---------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------
 // delta[tok][head] = sum_d dO * O   (needed only when a window has more than one key tile).  One 16-byte chunk of
@@ -1411,6 +1604,14 @@ int launch_fwd(const void* qkv, const float* bias_t, void* out, float* lse, cons
       const int gx = nwin < 512 ? nwin : 512;
       hipLaunchKernelGGL((attn_fwd_fast_kernel<T, HD, NW>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
                          (const T*)qkv, bias_t, (T*)out, lse, g, nwin);
+      return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+    }
+  }
+  if constexpr (Lay<T, HD>::DCH >= 4 && Lay<T, HD>::DCH <= 16) {
+    if (g.nqt > 1 && (g.nqt % 4) == 0) {
+      const long nb = (long)g.B * g.nwy * g.nwx * (g.nqt / 4) * g.heads;
+      hipLaunchKernelGGL((attn_fwd_mt_kernel<T, HD>), dim3((unsigned)nb), dim3(256), 0, st,
+                         (const T*)qkv, bias_t, (T*)out, lse, g);
       return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
     }
   }
