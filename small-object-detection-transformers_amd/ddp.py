@@ -4,9 +4,11 @@ The reference wraps the model in torch DDP (Train.py:264-266: bucketed mean all-
 22,007,851 f32 gradients per backward, call site C1 of SURVEY.md section 2.3) and
 compensates with ``loss *= world_size`` (Train.py:439-440), i.e. the optimizer sees the
 SUM over ranks of per-rank-mean gradients.  The engine already keeps every gradient in one
-contiguous f32 buffer, so the exchange is a single large collective (88 MB: ~1 ms ring-bound
-on 7 x 153 GB/s links, against tens of ms of backward) issued right after the last weight
-gradient is written.  ``average=True`` gives the conventional mean instead.
+contiguous f32 buffer, so the exchange is two large collectives: the tail of the buffer
+(PatchMerging 1, stages 2-3, necks, head: 83 % of the bytes) is complete before the stage-1
+backward starts and is all-reduced asynchronously under it (``reduce_async``); the rest follows
+the last weight gradient (``finish``).  88 MB are ~1 ms ring-bound on 7 x 153 GB/s links against
+~30 ms of backward.  ``average=True`` gives the conventional mean instead.
 
 torch.distributed's "nccl" backend IS RCCL on ROCm; tests cover the same code with gloo.
 """
@@ -24,12 +26,35 @@ class GradReducer:
         self.world = dist.get_world_size(group)
         self.average = average
 
+        self._pending = []     # (work handle, tensor) of collectives launched by reduce_async
+
     def reduce(self, flat_grad: torch.Tensor) -> None:
         if self.world == 1:
             return
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         if self.average:
             flat_grad.mul_(1.0 / self.world)
+
+    def reduce_async(self, part: torch.Tensor) -> None:
+        """Start the all-reduce of a finished slice of the gradient buffer; it runs on the backend's own stream, ordered
+        after the work already queued on the current stream, while later kernels keep the GPU busy.  Nothing may write
+        the slice until finish()."""
+        if self.world == 1:
+            return
+        self._pending.append((dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True), part))
+
+    def finish(self, rest: torch.Tensor) -> None:
+        """All-reduce the remaining slice, then make the current stream wait for the asynchronous ones."""
+        if self.world == 1:
+            return
+        dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=self.group)
+        if self.average:
+            rest.mul_(1.0 / self.world)
+        for work, part in self._pending:
+            work.wait()
+            if self.average:
+                part.mul_(1.0 / self.world)
+        self._pending = []
 
 
 def attach(model, group=None, average: bool = False, broadcast: bool = True):

@@ -32,6 +32,7 @@ class Plan:
     def __init__(self, B, S, dt, training, dev):
         self.B, self.S, self.dt, self.training, self.dev = B, S, dt, training, dev
         self.bufs: Dict[str, torch.Tensor] = {}
+        self.bwd_split: Optional[int] = None      # index in bwd_main where the stage-1 backward starts
         self.fwd_pre: Optional[list] = None
         self.fwd_main: Optional[list] = None
         self.bwd_main: Optional[list] = None
@@ -124,6 +125,10 @@ class Engine:
             p = self.params[n]
             self.g[n] = self.flat_grad[offs[n]: offs[n] + p.numel()].view(p.shape)
         self.grad_offsets = offs
+        # first element of the buffer's tail that is complete before the stage-1 backward (see _backward_main)
+        self.ddp_split = offs[next(n for n in self.grad_order if n.startswith(E + "pmerging1."))]
+        assert all(not n.startswith((E + "stage1.", E + "patch_embed.", E + "pos_embed", E + "channel_embed", E + "chan_block"))
+                   for n in self.grad_order if offs[n] >= self.ddp_split)
         fe = offs[E + "channel_embed_r.proj.weight"]
         self.g_fe_w = self.flat_grad[fe: fe + 4 * 48 * 16]
         self.g_fe_b = self.flat_grad[offs[E + "channel_embed_r.proj.bias"]:][: 4 * 48]
@@ -569,10 +574,16 @@ class Engine:
         # (1) Detect backward: live (dpred pointer changes)
         dzd = plan.buf("g.dzd", (T1, 48))
         ops.detect_unpermute(dpred, dzd, 48, B, t * t, self.na, self.no)
+        overlap = False
         if plan.bwd_main is None:
             with ops.Recorder() as rec:
                 self._backward_main(plan, P)
             plan.bwd_main = rec.calls
+        elif self.ddp is not None and self.ddp.world > 1 and getattr(plan, "bwd_split", None):
+            overlap = True
+            ops.replay(plan.bwd_main, probes=self.probes_bwd, end=plan.bwd_split)
+            self.ddp.reduce_async(self.flat_grad[self.ddp_split:])
+            ops.replay(plan.bwd_main, probes=self.probes_bwd, start=plan.bwd_split)
         else:
             ops.replay(plan.bwd_main, probes=self.probes_bwd)
         # (3) front end: live
@@ -588,7 +599,10 @@ class Engine:
             ops.cross_attn_ln_bwd(plan.bufs["fe.e"], fe["g"], plan.bufs["g.dx0"], de, self.g_fe_g, self.g_fe_be, B, S, ca_ws, ca_shift)
             ops.patch_embed4_bwd(x_rgb, x_ir, x_ir.shape[1] * S * S, de, self.g_fe_w, self.g_fe_b, B, S)
         if self.ddp is not None:
-            self.ddp.reduce(self.flat_grad)
+            if overlap:
+                self.ddp.finish(self.flat_grad[:self.ddp_split])
+            else:
+                self.ddp.reduce(self.flat_grad)
 
     def _backward_main(self, plan: Plan, P):
         B, S = plan.B, plan.S
@@ -643,6 +657,9 @@ class Engine:
         ops.gemm_tn(din7, [SegSpec(o4), SegSpec(o5)], g[E + "neck1.weight"], T1, 256, 384, ldy=384, y_off=128)
         df0 = SegSpec(din7, 256, 128)
         ops.gemm_nt([df0], wT[E + "neck1.weight"], dA, T1, 192, 256, w_off=192 * 256, resid=dA)        # d out5 += df0 @ Wn1[:,192:]
+        # every gradient from PatchMerging 1 to the end of the flat buffer is final here: data-parallel runs start
+        # their all-reduce now, under the stage-1 backward (ddp.GradReducer.reduce_async)
+        plan.bwd_split = ops.recorded_count()
         self._block_bwd(plan, P, "stage1.5", enc.stage1[5], dA, dB)
         ops.gemm_nt([df0], wT[E + "neck1.weight"], dB, T1, 192, 256, resid=dB)                           # d out4 += df0 @ Wn1[:,:192]
         cur, other = dB, dA

@@ -39,6 +39,11 @@ class Recorder:
         return False
 
 
+def recorded_count() -> Optional[int]:
+    """Launches recorded so far by the active Recorder (None outside one): lets the engine mark split points."""
+    return None if _active_recorder is None else len(_active_recorder)
+
+
 _tag: str = ""          # label attached to recorded launches (set by the engine, read by bench probes)
 
 
@@ -47,12 +52,15 @@ def set_tag(tag: str) -> None:
     _tag = tag
 
 
-def replay(calls: Sequence[Tuple], stream: Optional[int] = None, probes: Optional[dict] = None) -> None:
-    """Re-issue recorded launches.  probes: {call index: (start_event, end_event)} -> the events are
+def replay(calls: Sequence[Tuple], stream: Optional[int] = None, probes: Optional[dict] = None,
+           start: int = 0, end: Optional[int] = None) -> None:
+    """Re-issue recorded launches [start, end).  probes: {call index: (start_event, end_event)} -> the events are
     recorded on the launch stream around that one kernel (bench.py's live roofline measurement)."""
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
+    if start or end is not None:
+        calls = calls[start:end]
     if probes:
-        for i, (fn, args, name, tag) in enumerate(calls):
+        for i, (fn, args, name, tag) in enumerate(calls, start):
             pr = probes.get(i)
             if pr is not None:
                 pr[0].record()

@@ -24,6 +24,14 @@ def _worker(rank, world, port, q):
     flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
     ddp.GradReducer(average=True).reduce(flat)
     ok2 = bool(torch.allclose(flat, torch.arange(10, dtype=torch.float32) * 1.5))
+    # bucketed form: tail asynchronously, head at the end (the engine's overlap with the stage-1 backward)
+    flat = torch.arange(100, dtype=torch.float32) * (rank + 1)
+    red = ddp.GradReducer(average=True)
+    red.reduce_async(flat[40:])
+    flat[:40] += 1.0                      # "later kernels" still write the head
+    red.finish(flat[:40])
+    ok2 = ok2 and bool(torch.allclose(flat[40:], torch.arange(100, dtype=torch.float32)[40:] * 1.5)) \
+        and bool(torch.allclose(flat[:40], torch.arange(40, dtype=torch.float32) * 1.5 + 1.0)) and not red._pending
     start, per = ddp.shard_batch(16, rank, world)
     ok3 = (start, per) == (rank * 8, 8)
     # attach(): parameters are broadcast from rank 0
