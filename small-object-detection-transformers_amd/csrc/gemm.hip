@@ -135,10 +135,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
   const int fr = lane & 15, fg = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk && !(CF < 0 && (g.flags & (1 << 22)))) load_regs(kt + 1);
+    if (kt + 1 < nk) load_regs(kt + 1);
     const unsigned char* a_s = sA + buf * STAGE_BYTES;
     const unsigned char* b_s = sB + buf * STAGE_BYTES;
-    if (!(CF < 0 && (g.flags & (1 << 21))))
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       uint4 fa[4], fb[4];
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const sodt_gemm_args g)
       const float4 t = *(const float4*)(sC + r * EPI_LD + c + j);
       v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
     }
-    if (!(CF < 0 && (g.flags & (1 << 20)))) epi_chunk<T, CF>(g, flags, m, n, v, hw);
+    epi_chunk<T, CF>(g, flags, m, n, v, hw);
   }
 }
 
@@ -304,13 +303,13 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(const sodt_gemm_args g)
     const int n0 = jt * BN_;
     store_w();
     __syncthreads();                                   // A (first pass) and W(jt) visible
-    if (jt + 1 < ntiles && !(flags & (1 << 22))) load_w(n0 + BN_);   // in flight under the MFMAs + epilogue
+    if (jt + 1 < ntiles) load_w(n0 + BN_);   // in flight under the MFMAs + epilogue
     f32x4 acc[2][NSUB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NSUB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kb = 0; kb < ((flags & (1 << 21)) ? 0 : nkb); ++kb) {
+    for (int kb = 0; kb < nkb; ++kb) {
       const int ch = kb * 4 + fg;
       uint4 fa[2], fb[NSUB];
 #pragma unroll
@@ -360,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(const sodt_gemm_args g)
         const float4 t = *(const float4*)(sC + r * ELD + c + j);
         v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
       }
-      if (!(flags & (1 << 20))) epi_chunk<T>(g, flags, m, n, v, hw);
+      epi_chunk<T>(g, flags, m, n, v, hw);
     }
     __syncthreads();                                   // staging consumed before the next W tile lands
   }

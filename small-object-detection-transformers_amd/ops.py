@@ -131,7 +131,7 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
             gelu_out: Optional[torch.Tensor] = None, dgelu_aux: Optional[torch.Tensor] = None,
             stats: Optional[torch.Tensor] = None, affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
             out_f32: bool = False, detect: Optional[Tuple[int, int, int]] = None,
-            oscatter: Optional[Tuple[int, int, int, int, int]] = None, w_off: int = 0, debug_flags: int = 0,
+            oscatter: Optional[Tuple[int, int, int, int, int]] = None, w_off: int = 0,
             gelu_only: bool = False, dgelu_rc: bool = False) -> None:
     """out[M][N] = epilogue(concat_k(segs) @ W[N][K]^T); see SODT_EPI_* in include/sodt_hip.h."""
     g = L.GemmArgs()
@@ -177,7 +177,7 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
         flags |= L.EPI_GELU
     if dgelu_rc:
         flags |= L.EPI_DGELU_RC
-    g.M, g.N, g.K, g.flags = M, N, K, flags | debug_flags
+    g.M, g.N, g.K, g.flags = M, N, K, flags
     _launch("sodt_gemm_nt", C.byref(g), dt_code(W))
 
 
