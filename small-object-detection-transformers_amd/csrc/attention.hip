@@ -360,6 +360,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
     __syncthreads();
     FWD_ISSUE(item + (int)gridDim.x < nwin_total ? item + (int)gridDim.x : item)
 
+    // the window body is compiled twice (see attn_bwd_fast2_kernel): only the last window row / column of a shifted
+    // block mixes mask regions, and a run-time test per element is if-converted into compares + selects for everyone
+    auto body = [&](auto MSK_) {
+    constexpr bool MSK = decltype(MSK_)::value;
     // ---- S^T = K Q^T
     f32x4 s[4][4];
 #pragma unroll
@@ -379,14 +383,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
     // ---- softmax over keys for query (ms, fr): 16 in-lane values, then across the four 16-lane groups
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) {
-      const int qrid = msk ? (int)sRid[ms * 16 + fr] : 0;
+      const int qrid = MSK ? (int)sRid[ms * 16 + fr] : 0;
       float mx = -1e30f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = fmaf(s[ks][ms][r], scale2, bias2[ks][ms][r]);
-          if (msk && qrid != (int)sRid[ks * 16 + fg * 4 + r]) v += -100.0f * SODT_LOG2E;
+          if constexpr (MSK) { if (qrid != (int)sRid[ks * 16 + fg * 4 + r]) v += -100.0f * SODT_LOG2E; }
           s[ks][ms][r] = v;
           mx = fmaxf(mx, v);
         }
@@ -436,6 +440,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) st_elem<T>(myQ + qn * L::QROW + (d * 16 + fr) * E, o[ms][d][r] * inv);
       }
+    };
+    if (msk) body(std::true_type{}); else body(std::false_type{});
     __syncthreads();
     for (int idx = tid; idx < 64 * CPR; idx += NT) {
       const int r = idx / CPR, cc = idx - r * CPR;
@@ -1181,9 +1187,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int d = 0; d < HD / 16; ++d) { dk[i][d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // the window's strips, compiled twice: only windows in the last window row / column of a shifted block see more than
+    // one mask region (backbone_vit.py:1061-1072); a run-time test inside the softmax is if-converted by hipcc into
+    // 64 compares + 64 selects + 64 ors per window for everyone
+    auto strips = [&](auto MSK_) {
+    constexpr bool MSK = decltype(MSK_)::value;
     int krid[4];
 #pragma unroll
-    for (int ns = 0; ns < 4; ++ns) krid[ns] = msk ? (int)sGeoQ[ns * 16 + fr][2] : 0;
+    for (int ns = 0; ns < 4; ++ns) krid[ns] = MSK ? (int)sGeoQ[ns * 16 + fr][2] : 0;
 #pragma unroll
     for (int kbq = 0; kbq < 4 / SPK; ++kbq) {
       // B operands of the query contractions for this k-block (rows = the strip pair, transposed read)
@@ -1215,12 +1226,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
         for (int r = 0; r < 4; ++r) {
           const int qn = ms * 16 + fg * 4 + r;
           const float lq = sLse[w][qn];
-          const int qrid = msk ? (int)sGeoQ[qn][2] : 0;
+          const int qrid = MSK ? (int)sGeoQ[qn][2] : 0;
           float dl = 0.f;
 #pragma unroll
           for (int ns = 0; ns < 4; ++ns) {
             float v = fmaf(s[ns][r], scale2, bias2[ms - ns + 3][r]);
-            if (msk && qrid != krid[ns]) v += -100.0f * SODT_LOG2E;
+            if constexpr (MSK) { if (qrid != krid[ns]) v += -100.0f * SODT_LOG2E; }
             const float p = fast_exp2(v - lq);
             s[ns][r] = p;
             dl = fmaf(p, dp[ns][r], dl);
@@ -1274,6 +1285,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
             st_elem<T>(myDQ + (ms * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dq[d][r] * scale);
       }
     }
+    };
+    if (msk) strips(std::true_type{}); else strips(std::false_type{});
     // ---- stage dQ / dK / dV through this head's own Q / K / V tiles, then coalesced stores
 #pragma unroll
     for (int i = 0; i < 4; ++i)
