@@ -65,10 +65,14 @@ template <> __device__ __forceinline__ void unpack<bf16>(const uint4& u, float* 
   f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
   f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
 }
+// two floats -> one dword of packed bf16 (RNE): a single v_cvt_pk_bf16_f32 (scalar casts + shift/or cost four VALU ops)
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  union { bf16 b; uint16_t u; } a, b;
-  a.b = (bf16)lo; b.b = (bf16)hi;
-  return (uint32_t)a.u | ((uint32_t)b.u << 16);
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+  const f32x2_ f = {lo, hi};
+  union { bf16x2_ v; uint32_t u; } r;
+  r.v = __builtin_convertvector(f, bf16x2_);
+  return r.u;
 }
 template <typename T> __device__ __forceinline__ uint4 pack(const float* f);
 template <> __device__ __forceinline__ uint4 pack<float>(const float* f) {
