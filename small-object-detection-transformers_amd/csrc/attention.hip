@@ -367,10 +367,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
     // ---- S^T = K Q^T
     f32x4 s[4][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int ms = 0; ms < 4; ++ms) s[ks][ms] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
     for (int kb = 0; kb < L::KBQ; ++kb) {
       uint4 fk[4], fq[4];
 #pragma unroll
@@ -378,7 +374,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int ms = 0; ms < 4; ++ms) mma16<T>(s[ks][ms], fk[ks], fq[ms]);
+        for (int ms = 0; ms < 4; ++ms) {
+          if (kb == 0) s[ks][ms] = mma16z<T>(fk[ks], fq[ms]); else mma16<T>(s[ks][ms], fk[ks], fq[ms]);
+        }
     }
     // ---- softmax over keys for query (ms, fr): 16 in-lane values, then across the four 16-lane groups
 #pragma unroll
@@ -873,8 +871,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
       for (int ms = 0; ms < 4; ++ms) {
         f32x4 s[4], dp[4];
 #pragma unroll
-        for (int ns = 0; ns < 4; ++ns) { s[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
         for (int kb = 0; kb < L::KBQ; ++kb) {
           const uint4 fq = frag<T>(myQ, L::QROW, ms * 16, kb, HD, lane);
           const uint4 fo = frag<T>(myDO, L::QROW, ms * 16, kb, HD, lane);
@@ -882,8 +878,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const T* __restrict__
           for (int ns = 0; ns < 4; ++ns) {
             const uint4 fk = frag<T>(myK, L::QROW, ns * 16, kb, HD, lane);
             const uint4 fv = frag<T>(myV, L::QROW, ns * 16, kb, HD, lane);
-            mma16<T>(s[ns], fq, fk);
-            mma16<T>(dp[ns], fo, fv);
+            if (kb == 0) { s[ns] = mma16z<T>(fq, fk); dp[ns] = mma16z<T>(fo, fv); }
+            else { mma16<T>(s[ns], fq, fk); mma16<T>(dp[ns], fo, fv); }
           }
         }
 #pragma unroll
@@ -1209,8 +1205,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
         const int ms = kbq * SPK + hh;
         f32x4 s[4], dp[4];
 #pragma unroll
-        for (int ns = 0; ns < 4; ++ns) { s[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
         for (int kb = 0; kb < L::KBQ; ++kb) {
           const uint4 fq = frag<T>(myQ, L::QROW, ms * 16, kb, HD, lane);
           const uint4 fo = frag<T>(myDO, L::QROW, ms * 16, kb, HD, lane);
@@ -1218,8 +1212,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
           for (int ns = 0; ns < 4; ++ns) {
             const uint4 fk = frag<T>(myK, L::QROW, ns * 16, kb, HD, lane);
             const uint4 fv = frag<T>(myV, L::QROW, ns * 16, kb, HD, lane);
-            mma16<T>(s[ns], fq, fk);
-            mma16<T>(dp[ns], fo, fv);
+            if (kb == 0) { s[ns] = mma16z<T>(fq, fk); dp[ns] = mma16z<T>(fo, fv); }
+            else { mma16<T>(s[ns], fq, fk); mma16<T>(dp[ns], fo, fv); }
           }
         }
 #pragma unroll
@@ -1271,12 +1265,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
         // B = K read transposed from its tile; finished strips go straight to the dQ staging tile
         f32x4 dq[HD / 16];
 #pragma unroll
-        for (int d = 0; d < HD / 16; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
         for (int kb = 0; kb < L::KBT; ++kb) {
           const uint4 fst = fragT<T>(myDS, DSROW, kb * MK, 0, lane);
 #pragma unroll
-          for (int d = 0; d < HD / 16; ++d) mma16<T>(dq[d], fst, fragT<T>(myK, L::QROW, kb * MK, d * 16, lane));
+          for (int d = 0; d < HD / 16; ++d) {
+            const uint4 fkk = fragT<T>(myK, L::QROW, kb * MK, d * 16, lane);
+            if (kb == 0) dq[d] = mma16z<T>(fst, fkk); else mma16<T>(dq[d], fst, fkk);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -1477,8 +1472,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mt_kernel(const T* __restric
           const int ms = kbq * SPK + hh;
           f32x4 s[4], dp[4];
 #pragma unroll
-          for (int ns = 0; ns < 4; ++ns) { s[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[ns] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
           for (int kb = 0; kb < L::KBQ; ++kb) {
             const uint4 fq = frag<T>(myQ, L::QROW, ms * 16, kb, HD, lane);
             const uint4 fo = frag<T>(myDO, L::QROW, ms * 16, kb, HD, lane);
@@ -1486,8 +1479,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mt_kernel(const T* __restric
             for (int ns = 0; ns < 4; ++ns) {
               const uint4 fk = frag<T>(myK, L::QROW, ns * 16, kb, HD, lane);
               const uint4 fv = frag<T>(myV, L::QROW, ns * 16, kb, HD, lane);
-              mma16<T>(s[ns], fq, fk);
-              mma16<T>(dp[ns], fo, fv);
+              if (kb == 0) { s[ns] = mma16z<T>(fq, fk); dp[ns] = mma16z<T>(fo, fv); }
+              else { mma16<T>(s[ns], fq, fk); mma16<T>(dp[ns], fo, fv); }
             }
           }
 #pragma unroll
@@ -1523,12 +1516,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mt_kernel(const T* __restric
           // dQ strip ms = dS K, added to the f32 accumulator of the window straight from the MFMA accumulators
           f32x4 dq[HD / 16];
 #pragma unroll
-          for (int d = 0; d < HD / 16; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
           for (int kb = 0; kb < L::KBT; ++kb) {
             const uint4 fst = fragT<T>(myDS, DSROW, kb * MK, 0, lane);
 #pragma unroll
-            for (int d = 0; d < HD / 16; ++d) mma16<T>(dq[d], fst, fragT<T>(myK, L::QROW, kb * MK, d * 16, lane));
+            for (int d = 0; d < HD / 16; ++d) {
+              const uint4 fkk = fragT<T>(myK, L::QROW, kb * MK, d * 16, lane);
+              if (kb == 0) dq[d] = mma16z<T>(fst, fkk); else mma16<T>(dq[d], fst, fkk);
+            }
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

@@ -54,6 +54,21 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
+// first update of a tile: C is the inline constant 0 (no v_mov zero-initialisation of the accumulator)
+template <typename T> __device__ __forceinline__ f32x4 mma16z(const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ f32x4 mma16z<bf16>(const uint4& a, const uint4& b) {
+  union { uint4 u; bf16x8 v; } ua, ub;
+  ua.u = a; ub.u = b;
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma16z<float>(const uint4& a, const uint4& b) {
+  f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  return acc;
+}
+
 // 16-byte chunk <-> KPL floats
 template <typename T> __device__ __forceinline__ void unpack(const uint4& u, float* f);
 template <> __device__ __forceinline__ void unpack<float>(const uint4& u, float* f) {
