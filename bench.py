@@ -91,12 +91,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    # rehearsal hooks (one-GPU box): SODT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, SODT_BENCH_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device); the real run uses one GPU per rank and the nccl (= RCCL) backend
+    if os.environ.get("SODT_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("SODT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     B, S = a.batch, a.size
