@@ -1079,7 +1079,7 @@ template <> __device__ __forceinline__ uint4 fragTp<float>(const unsigned char* 
 }
 
 template <typename T, int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
                                                                 const T* __restrict__ d_out, const float* __restrict__ lse,
                                                                 T* __restrict__ dqkv, float* __restrict__ dbias_t,
                                                                 const AttnGeo g, int nwin_total) {
@@ -1088,11 +1088,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
   constexpr int SPK = MK / 16;                  // 16-query strips per MFMA k-block: 2 (bf16) or 1 (f32)
   constexpr int DSROW = 16 * E + 16;            // [key][16 q] patch row (bytes)
   constexpr int LTMAX = 225;
+  constexpr bool LATE_PF = NW == 4;             // four-head workgroups run two per CU (see the launch bounds)
   __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE], sK[NW * L::QTILE], sV[NW * L::QTILE],
       sDO[NW * L::QTILE];
   __shared__ __attribute__((aligned(16))) unsigned char sDS[NW * 64 * DSROW];
   __shared__ __attribute__((aligned(16))) unsigned char sDQ[NW * L::QTILE];      // dQ staging (Q stays live to the end)
-  __shared__ float sDB[NW][LTMAX + 3];
+  __shared__ float sDB[NW][LTMAX + 3];       // bias values x log2 e during the walk, bias-gradient table at the end
   __shared__ float sLse[NW][64];
   __shared__ int sTokQ[64];
   __shared__ short sGeoQ[64][4];
@@ -1108,23 +1109,23 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
   unsigned char* myV = sV + w * L::QTILE; unsigned char* myDO = sDO + w * L::QTILE;
   unsigned char* myDS = sDS + w * 64 * DSROW;
   unsigned char* myDQ = sDQ + w * L::QTILE;
-  for (int i = tid; i < NW * (LTMAX + 3); i += NT) (&sDB[0][0])[i] = 0.f;
 
   // 8x8 windows: a 16-token strip is two window rows, so the table entry of (q, key) depends on the strips only
   // through ms - ns:  qy - ky = 2 (ms - ns) + ((4 fg + r) >> 3) - (fr >> 3),  qx - kx = ((4 fg + r) & 7) - (fr & 7).
   // Bias values and bias-gradient sums are therefore kept per strip DIFFERENCE (7 x 4 registers each, not 64).
   f32x4 dbc[7];
-  float bias2[7][4];
 #pragma unroll
-  for (int dc = 0; dc < 7; ++dc) {
-    dbc[dc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int dc = 0; dc < 7; ++dc) dbc[dc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias values (x log2 e) of this head in LDS; lane (fg, fr) / accumulator row r reads entry (dy + 7) * 15 + dx + 7 with
+  // dy = 2 (ms - ns) + ((4 fg + r) >> 3) - (fr >> 3), dx = ((4 fg + r) & 7) - (fr & 7): one base address per r, the strip
+  // difference is an immediate offset of 120 bytes per step
+  for (int i = lane; i < LT; i += 64) sDB[w][i] = bt[i] * SODT_LOG2E;
+  uint32_t bAddr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int dy = 2 * (dc - 3) + ((4 * fg + r) >> 3) - (fr >> 3), dx = ((4 * fg + r) & 7) - (fr & 7);
-      bias2[dc][r] = (dy > -8 && dy < 8) ? bt[(dy + 7) * L2 + dx + 7] * SODT_LOG2E : 0.f;
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int dy0 = -6 + ((4 * fg + r) >> 3) - (fr >> 3), dx = ((4 * fg + r) & 7) - (fr & 7);   // strip difference -3
+    bAddr[r] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sDB[w][(dy0 + 7) * L2 + dx + 7];
   }
-
   uint4 pq0, pq1, pq2, pq3, pk0, pk1, pk2, pk3, pv0, pv1, pv2, pv3, pd0, pd1, pd2, pd3;
   float plse = 0.f;
 #define B2_ISSUE_ONE(i, ITEM)                                                           \
@@ -1173,7 +1174,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
     B2_STORE_ONE(0) B2_STORE_ONE(1) B2_STORE_ONE(2) B2_STORE_ONE(3)
     sLse[w][lane] = plse * SODT_LOG2E;
     __syncthreads();
-    {
+    if constexpr (!LATE_PF) {
       const int nxt = item + (int)gridDim.x < nwin_total ? item + (int)gridDim.x : item;
       B2_ISSUE(nxt)
     }
@@ -1224,7 +1225,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
           float dl = 0.f;
 #pragma unroll
           for (int ns = 0; ns < 4; ++ns) {
-            float v = fmaf(s[ns][r], scale2, bias2[ms - ns + 3][r]);
+            float v = fmaf(s[ns][r], scale2, *(const float*)((const __attribute__((address_space(3))) char*)(uintptr_t)bAddr[r] + 120 * (ms - ns + 3)));
             if constexpr (MSK) { if (qrid != krid[ns]) v += -100.0f * SODT_LOG2E; }
             const float p = fast_exp2(v - lq);
             s[ns][r] = p;
@@ -1282,6 +1283,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
     }
     };
     if (msk) strips(std::true_type{}); else strips(std::false_type{});
+    if constexpr (LATE_PF) {   // next window's Q / K / V / dO chunks + lse: issued after the strips so the 33 prefetch
+        // registers are not live across the register-heaviest part of the kernel (234 VGPRs: two workgroups per CU, no
+        // AGPR copies); they land under the staging / store phase and the other workgroup's compute
+      const int nxt = item + (int)gridDim.x < nwin_total ? item + (int)gridDim.x : item;
+      B2_ISSUE(nxt)
+    }
     // ---- stage dQ / dK / dV through this head's own Q / K / V tiles, then coalesced stores
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1306,6 +1313,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fast2_kernel(const T* __rest
   }
   // ---- bias gradient: one reduction for all the windows this wave handled (window-local geometry is the same
   //      for every window): registers -> LDS table -> global atomics
+  __syncthreads();
+  for (int i = tid; i < NW * (LTMAX + 3); i += NT) (&sDB[0][0])[i] = 0.f;
   __syncthreads();
   if (nwin_total > (int)blockIdx.x) {
 #pragma unroll
