@@ -45,7 +45,7 @@ def build_model(S, dev, dtype):
     return model
 
 
-def cpu_baseline(S=1024, sample_S=512, iters=2):
+def cpu_baseline(S=1024, sample_S=512, iters=10):
     """Oracle fwd+bwd on the host cores on a bounded sample: `iters` timed images at sample_S x sample_S after one
     warm-up.  The path's cost is linear in pixels (fixed 8x8 / 32x32 windows), so the figure is
     scaled by (sample_S / S)^2 to the benchmark resolution; both numbers are reported."""
