@@ -1096,8 +1096,7 @@ extern "C" int sodt_gemm_tn(const sodt_gemm_tn_args* g, int dtype, sodt_stream_t
   if (!aspec_ok(g->x, g->K, kpl)) return SODT_EINVAL;
   if ((g->ldy % kpl) || g->ldy < (g->N + kpl - 1) / kpl * kpl || (((uintptr_t)g->dY) & 15)) return SODT_EINVAL;
   if (g->kperm_t > 1 && (g->kperm_c <= 0 || g->kperm_c * g->kperm_t != g->K)) return SODT_EINVAL;
-  if (dtype == SODT_BF16 && g_variant == 0 && (g->N % 8) == 0 && (g->K % 8) == 0 && g->M >= 1024 &&
-      !(g->N < 192 && g->K > 768))     // narrow-N, long-K head shapes pad the 256 x 192 tile too much
+  if (dtype == SODT_BF16 && g_variant == 0 && (g->N % 8) == 0 && (g->K % 8) == 0 && g->M >= 1024)
     return sodt_tn3_launch(g, (hipStream_t)st);
   if (!g_force_tiled && (g->N <= 192 || g->K <= 192)) {   // short side <= 192: the 256 x 192 tile reads each operand (almost) once
     if (dtype == SODT_BF16) return launch_tn2<bf16>(g, (hipStream_t)st);

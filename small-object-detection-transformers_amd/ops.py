@@ -192,7 +192,7 @@ def tn_splits(M: int, N: int, K: int, bf16: bool = False) -> int:
     workgroup per CU when the short side is <= 192, 128 x 128 tiles at two per CU otherwise (csrc/gemm.hip).
     bf16 (M >= 1024): the pipelined kernel of csrc/gemm3.hip - 256 x 192 tiles, the 256 side on whichever of
     N / K pads less, one workgroup per CU, at least 16 stages of 32 rows per workgroup."""
-    if bf16 and M >= 1024 and N % 8 == 0 and K % 8 == 0 and not (N < 192 and K > 768):
+    if bf16 and M >= 1024 and N % 8 == 0 and K % 8 == 0:
         a = ((N + 255) // 256) * ((K + 191) // 192)
         b = ((K + 255) // 256) * ((N + 191) // 192)
         tiles = b if b * 256 * 192 < a * 256 * 192 else a
