@@ -32,7 +32,9 @@ class Plan:
     def __init__(self, B, S, dt, training, dev):
         self.B, self.S, self.dt, self.training, self.dev = B, S, dt, training, dev
         self.bufs: Dict[str, torch.Tensor] = {}
-        self.bwd_split: Optional[int] = None      # index in bwd_main where the stage-1 backward starts
+        self.bwd_marks: List[Tuple[int, int, int]] = []   # (index in bwd_main, first, last+1 element of flat_grad) of the
+        #                                                   gradient buckets that are final at that launch (ddp overlap)
+        self.gen = 0                              # bumped by every forward that overwrites the saved activations
         self.fwd_pre: Optional[list] = None
         self.fwd_main: Optional[list] = None
         self.bwd_main: Optional[list] = None
@@ -47,6 +49,41 @@ class Plan:
         return t
 
 
+class _LazyFeatures(list):
+    """forward_once's feature list `y` (model.py:268-281).  Entries 4, 5, 8, 9 - nn.Upsample(x2, nearest) of y[3] / y[7]
+    and their Concat with y[1] / y[0] (models/model.yaml:66-67,71-72) - are index arithmetic inside the GEMM loaders
+    and never exist in the workspace; they are computed on first access."""
+    _RULES = {4: ("up", 3), 8: ("up", 7), 5: ("cat", 4, 1), 9: ("cat", 8, 0)}
+
+    def _fill(self, i):
+        if list.__getitem__(self, i) is None and i in self._RULES:
+            r = self._RULES[i]
+            if r[0] == "up":
+                v = torch.nn.functional.interpolate(self[r[1]].float(), scale_factor=2, mode="nearest")
+            else:
+                v = torch.cat((self[r[1]], self[r[2]].float()), 1)
+            list.__setitem__(self, i, v)
+
+    def __getitem__(self, i):
+        if isinstance(i, int):
+            j = i + len(self) if i < 0 else i
+            self._fill(j)
+        else:
+            for j in self._RULES:
+                self._fill(j)
+        return list.__getitem__(self, i)
+
+    def __iter__(self):
+        for j in self._RULES:
+            self._fill(j)
+        return list.__iter__(self)
+
+    def __add__(self, other):       # Model.forward appends the head output: stay lazy
+        out = _LazyFeatures(list.__iter__(self))
+        list.extend(out, other)
+        return out
+
+
 class _EngineFn(torch.autograd.Function):
     """One autograd node for the whole model.  Parameter gradients are written straight into
     ``param.grad`` (views of the engine's flat buffer), so the node returns None for them."""
@@ -56,10 +93,15 @@ class _EngineFn(torch.autograd.Function):
         ctx.engine, ctx.plan = engine, plan
         ctx.inputs = (x_rgb, x_ir)
         pred = engine._forward(plan, x_rgb, x_ir)
+        ctx.gen = plan.gen
         return pred
 
     @staticmethod
     def backward(ctx, dpred):
+        if ctx.gen != ctx.plan.gen:
+            raise RuntimeError("the activations this backward needs were overwritten by a later forward of the same "
+                               "(batch, resolution, dtype, mode): call backward() before the next forward, or run the "
+                               "extra forward under model.eval() / torch.no_grad() with a different mode")
         ctx.engine._backward(ctx.plan, ctx.inputs[0], ctx.inputs[1], dpred.contiguous().float())
         return None, None, None, None, None
 
@@ -113,7 +155,17 @@ class Engine:
     def _build_grad_buffer(self):
         order = [E + f"channel_embed_{c}.proj.weight" for c in "rgbi"] + [E + f"channel_embed_{c}.proj.bias" for c in "rgbi"]
         order += [E + f"chan_block.norm{i}.weight" for i in range(1, 5)] + [E + f"chan_block.norm{i}.bias" for i in range(1, 5)]
-        rest = [n for n in self.params if n not in set(order)]
+        # the rest in REVERSE order of completion in the backward, so that the buckets that become final first are
+        # contiguous slices at the end of the buffer (ddp.py): [front end | pos/patch embed | stage 1 | PatchMerging 1,
+        # neck 1 | stage 2 | PatchMerging 2, neck 2 | stage 3 | neck 3 | head]
+        groups = [E + "pos_embed", E + "patch_embed.", E + "stage1.", E + "pmerging1.", E + "neck1.", E + "stage2.",
+                  E + "pmerging2.", E + "neck2.", E + "stage3.", E + "neck3.", "detect."]
+        seen = set(order)
+        rest = []
+        for gname in groups:
+            rest += [n for n in self.params if n.startswith(gname) and n not in seen]
+            seen.update(rest)
+        rest += [n for n in self.params if n not in seen]      # nothing today; keeps unknown parameters reducible
         self.grad_order = order + rest
         offs, tot = {}, 0
         for n in self.grad_order:
@@ -127,6 +179,9 @@ class Engine:
         self.grad_offsets = offs
         # first element of the buffer's tail that is complete before the stage-1 backward (see _backward_main)
         self.ddp_split = offs[next(n for n in self.grad_order if n.startswith(E + "pmerging1."))]
+        self.ddp_split3 = offs[next(n for n in self.grad_order if n.startswith(E + "stage3."))]
+        assert self.ddp_split < self.ddp_split3 and all(
+            n.startswith((E + "stage3.", E + "neck3.", "detect.")) for n in self.grad_order if offs[n] >= self.ddp_split3)
         assert all(not n.startswith((E + "stage1.", E + "patch_embed.", E + "pos_embed", E + "channel_embed", E + "chan_block"))
                    for n in self.grad_order if offs[n] >= self.ddp_split)
         fe = offs[E + "channel_embed_r.proj.weight"]
@@ -223,18 +278,28 @@ class Engine:
         ops.prep_weights(tf, nf, mf, L.F32)
 
     # ------------------------------------------------------------------ public entry
+    MAX_PLANS = 4      # each plan owns a full activation workspace (31 GB at B=8 @1024^2 bf16): least recently used goes
+
     def run(self, x_rgb, x_ir, dt, training):
         if x_rgb.dim() != 4 or x_rgb.shape[1] != 3 or x_ir.dim() != 4 or x_rgb.shape[-1] != x_rgb.shape[-2]:
             raise ValueError("expected x_rgb (B,3,S,S) and x_ir (B,>=1,S,S)")
         B, _, S, _ = x_rgb.shape
         if S % 32:
             raise ValueError("S must be a multiple of 32 (4x patch stride, 8x8 windows on t/2 .. even t/4)")
+        if x_ir.shape[0] != B or x_ir.shape[1] < 1 or tuple(x_ir.shape[-2:]) != (S, S):
+            raise ValueError(f"x_ir must be (B={B}, >=1, {S}, {S}) like x_rgb, got {tuple(x_ir.shape)}")
+        if x_rgb.device != self.dev or x_ir.device != self.dev:
+            raise ValueError(f"inputs must be on the model's device {self.dev} (got {x_rgb.device}, {x_ir.device}): "
+                             "the kernels take raw device pointers")
         x_rgb = x_rgb.float().contiguous()
         x_ir = x_ir.float().contiguous()
         key = (B, S, dt, training)
-        plan = self.plans.get(key)
+        plan = self.plans.pop(key, None)
         if plan is None:
-            plan = self.plans[key] = Plan(B, S, dt, training, self.dev)
+            while len(self.plans) >= self.MAX_PLANS:
+                self.plans.pop(next(iter(self.plans)))          # dicts keep insertion order: the first key is the LRU one
+            plan = Plan(B, S, dt, training, self.dev)
+        self.plans[key] = plan                                   # (re)insert as most recently used
         if training and torch.is_grad_enabled():
             pred = _EngineFn.apply(self, plan, x_rgb, x_ir, self._anchor)
         else:
@@ -250,21 +315,20 @@ class Engine:
 
     def _features(self, plan):
         """y[0..10] of forward_once (model.py:246,281) as NCHW *views* of the workspace (valid until the
-        next forward).  y4,y5,y8,y9 (upsample / concat) are never materialised by the kernels; they are
-        built with torch only when model.materialize_features is set."""
+        next forward).  y4, y5, y8, y9 (upsample / concat) are never materialised by the kernels: the list
+        builds them with torch on first access (``_LazyFeatures``), so callers that index them get tensors
+        as in the reference and nobody else pays for them."""
         B, t = plan.B, plan.S // 4
         b = plan.bufs
 
         def nchw(name, h, c):
             return b[name].view(B, h, h, c).permute(0, 3, 1, 2)
-        y = [nchw("f0", t, 256), nchw("f1", t // 2, 256), nchw("f2", t // 4, 512), nchw("h0.y", t // 4, 256), None, None,
-             nchw("h3.cv3.y", t // 2, 256), nchw("h4.y", t // 2, 128), None, None, nchw("h7.cv3.y", t, 128)]
+        y = _LazyFeatures([nchw("f0", t, 256), nchw("f1", t // 2, 256), nchw("f2", t // 4, 512), nchw("h0.y", t // 4, 256),
+                           None, None, nchw("h3.cv3.y", t // 2, 256), nchw("h4.y", t // 2, 128), None, None,
+                           nchw("h7.cv3.y", t, 128)])
         if self.model.materialize_features:
-            import torch.nn.functional as F
-            y[4] = F.interpolate(y[3].float(), scale_factor=2, mode="nearest")
-            y[5] = torch.cat((y[4], y[1].float()), 1)
-            y[8] = F.interpolate(y[7].float(), scale_factor=2, mode="nearest")
-            y[9] = torch.cat((y[8], y[0].float()), 1)
+            for i in (4, 5, 8, 9):
+                y[i]
         return y
 
     # ================================================================== forward
@@ -272,6 +336,7 @@ class Engine:
         P = self._prep_for(plan.dt)
         B, S = plan.B, plan.S
         t = S // 4
+        plan.gen += 1          # the saved activations of an earlier forward on this plan are gone (see _EngineFn.backward)
         # (1) parameter preparation (recorded)
         if plan.fwd_pre is None:
             with ops.Recorder() as rec:
@@ -569,8 +634,11 @@ class Engine:
         B, S = plan.B, plan.S
         t = S // 4
         T1 = B * t * t
-        if self._claim_grads():
+        fresh = self._claim_grads()
+        if fresh:
             ops.zero_(self.flat_grad)
+        if self.ddp is not None:
+            self.ddp.begin_backward(self.flat_grad, fresh)
         # (1) Detect backward: live (dpred pointer changes)
         dzd = plan.buf("g.dzd", (T1, 48))
         ops.detect_unpermute(dpred, dzd, 48, B, t * t, self.na, self.no)
@@ -579,11 +647,15 @@ class Engine:
             with ops.Recorder() as rec:
                 self._backward_main(plan, P)
             plan.bwd_main = rec.calls
-        elif self.ddp is not None and self.ddp.world > 1 and getattr(plan, "bwd_split", None):
+        elif self.ddp is not None and self.ddp.world > 1 and self.ddp.sync and plan.bwd_marks:
+            # replay in segments: at every mark one more bucket of the flat buffer is final and its all-reduce starts
             overlap = True
-            ops.replay(plan.bwd_main, probes=self.probes_bwd, end=plan.bwd_split)
-            self.ddp.reduce_async(self.flat_grad[self.ddp_split:])
-            ops.replay(plan.bwd_main, probes=self.probes_bwd, start=plan.bwd_split)
+            pos = 0
+            for idx, lo, hi in plan.bwd_marks:
+                ops.replay(plan.bwd_main, probes=self.probes_bwd, start=pos, end=idx)
+                self.ddp.reduce_async(self.flat_grad[lo:hi])
+                pos = idx
+            ops.replay(plan.bwd_main, probes=self.probes_bwd, start=pos)
         else:
             ops.replay(plan.bwd_main, probes=self.probes_bwd)
         # (3) front end: live
@@ -638,6 +710,8 @@ class Engine:
         d3b = plan.buf("g.dB.768", (T3, 768))
         ops.gemm_nt([SegSpec(df2)], wT[E + "neck3.weight"], d3a, T3, 768, 512)
         self._block_bwd(plan, P, "stage3.0", enc.stage3[0], d3a, d3b)
+        # head, neck 3 and stage 3 gradients are final: first data-parallel bucket (ddp.GradReducer.reduce_async)
+        plan.bwd_marks.append((ops.recorded_count(), self.ddp_split3, self.flat_grad.numel()))
         # ---- pmerging2 -> d(stage2 out) ; + neck2
         dA = plan.buf("g.dA.384", (T2, 384))
         dB = plan.buf("g.dB.384", (T2, 384))
@@ -659,7 +733,7 @@ class Engine:
         ops.gemm_nt([df0], wT[E + "neck1.weight"], dA, T1, 192, 256, w_off=192 * 256, resid=dA)        # d out5 += df0 @ Wn1[:,192:]
         # every gradient from PatchMerging 1 to the end of the flat buffer is final here: data-parallel runs start
         # their all-reduce now, under the stage-1 backward (ddp.GradReducer.reduce_async)
-        plan.bwd_split = ops.recorded_count()
+        plan.bwd_marks.append((ops.recorded_count(), self.ddp_split, self.ddp_split3))
         self._block_bwd(plan, P, "stage1.5", enc.stage1[5], dA, dB)
         ops.gemm_nt([df0], wT[E + "neck1.weight"], dB, T1, 192, 256, resid=dB)                           # d out4 += df0 @ Wn1[:,:192]
         cur, other = dB, dA

@@ -41,7 +41,36 @@ def _worker(rank, world, port, q):
     lin._get_engine = lambda: None
     ddp.attach(lin, average=True)
     ok4 = bool(torch.all(lin.weight == 0.0)) and lin._pending_ddp.world == 2
-    q.put((rank, ok1 and ok2 and ok3 and ok4))
+    # gradient accumulation (Train.py:125,448: 4 micro-steps per optimizer step), the engine's protocol: the kernels ADD
+    # each backward's local gradient into the flat buffer, begin_backward() runs first, reduce() last
+    def micro(red, flat, k, fresh):
+        red.begin_backward(flat, fresh)
+        flat += float((rank + 1) * k)                     # this rank's gradient of micro-step k
+        red.reduce(flat)
+    ok5 = True
+    for average in (False, True):
+        want = sum((r + 1) * k for r in range(world) for k in (1, 2, 3)) / (world if average else 1)
+        # (a) reduce on every micro-step, as the reference's DDP does (no no_sync in Train.py)
+        red, flat = ddp.GradReducer(average=average), torch.zeros(8)
+        for k in (1, 2, 3):
+            micro(red, flat, k, fresh=(k == 1))
+        ok5 = ok5 and bool(torch.allclose(flat, torch.full((8,), want)))
+        # (b) torch DDP's idiom: no_sync() around all but the last micro-step
+        red, flat = ddp.GradReducer(average=average), torch.zeros(8)
+        with red.no_sync():
+            micro(red, flat, 1, fresh=True)
+            micro(red, flat, 2, fresh=False)
+        micro(red, flat, 3, fresh=False)
+        ok5 = ok5 and bool(torch.allclose(flat, torch.full((8,), want)))
+        # (c) mixed: reduced, then an unsynchronised step, then a synchronised one
+        red, flat = ddp.GradReducer(average=average), torch.zeros(8)
+        micro(red, flat, 1, fresh=True)
+        with red.no_sync():
+            micro(red, flat, 2, fresh=False)
+        micro(red, flat, 3, fresh=False)
+        ok5 = ok5 and bool(torch.allclose(flat, torch.full((8,), want)))
+    ok6 = ddp.GradReducer().average is True               # torch DDP's mean is the default (Train.py keeps loss *= world_size)
+    q.put((rank, ok1 and ok2 and ok3 and ok4 and ok5 and ok6))
     dist.destroy_process_group()
 
 
