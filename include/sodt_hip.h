@@ -136,6 +136,35 @@ int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const void* out, 
                          int B, int H, int W, int C, int heads, int ws, int shift,
                          int dtype, sodt_stream_t st);
 
+/* ---- fused W-MSA / SW-MSA half of a Swin block (csrc/wmsa_block.hip) -------------------------------------------
+ * x_mid = x + Proj(WindowAttention(LN1(x))) and xn2 = LN2(x_mid) in ONE launch: SwinTransformerBlock.forward
+ * backbone_vit.py:1084-1128 up to the MLP, with WindowAttention.forward :961-992, window_partition / unpartition
+ * :619-672 and both torch.roll :1096,1118 as index arithmetic.  Built for the stage-1 geometry of model.yaml
+ * (backbone_vit.py:117-133): C == 192, heads == 12 (head_dim 16), ws == 8, shift in [0, 8); H, W multiples of 8.
+ * Any other shape returns SODT_EINVAL (callers fall back to sodt_layernorm_fwd + sodt_gemm_nt + sodt_window_attn_fwd).
+ *
+ * sodt_wmsa_pack: the block's raw f32 parameters -> the kernel's streaming order (per head: Wq/Wk/Wv rows and the
+ *   Wproj column slice as MFMA fragments, the head's relative-position table x log2 e, q/k/v bias; then proj bias and
+ *   the two LayerNorms), cast to the run dtype.  rpb_table is relative_position_bias_table as stored: ((2ws-1)^2, heads).
+ *   wpk must hold sodt_wmsa_pack_bytes() bytes, 16-byte aligned.  Re-run whenever the parameters change.
+ * sodt_wmsa_block_fwd: x, xm, xn2 [B*H*W][C] run dtype, natural token order.  Training passes the save-for-backward
+ *   outputs (all or none): xn1 = LN1(x) [M][C]; st1 / st2 = (mean, rstd) of LN1 / LN2, f32 [M][2]; ao = attention
+ *   output before the projection [M][C]; qkvw = q|k|v in window-major order [window][head][3][64][16] run dtype and
+ *   lsew = log-sum-exp [window][head][64] f32, window = (b*(H/8) + wy)*(W/8) + wx in the shifted frame, token =
+ *   window-local row-major - the operands of sodt_window_attn_bwd_wm.  Pass xn1 == NULL for inference. */
+long sodt_wmsa_pack_bytes(int C, int heads, int ws, int dtype);
+int sodt_wmsa_pack(const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b,
+                   const float* rpb_table, const float* n1_w, const float* n1_b, const float* n2_w,
+                   const float* n2_b, void* wpk, int C, int heads, int ws, int dtype, sodt_stream_t st);
+int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, void* xn2, float* st1, float* st2,
+                        void* xn1, void* qkvw, float* lsew, void* ao,
+                        int B, int H, int W, int C, int heads, int ws, int shift, int dtype, sodt_stream_t st);
+/* sodt_window_attn_bwd on the window-major qkvw / lsew of sodt_wmsa_block_fwd (8x8 windows, head_dim 16);
+ * dout and dqkv keep the natural layouts [M][C] / [M][3C]. */
+int sodt_window_attn_bwd_wm(const void* qkvw, const float* bias_t, const void* dout, const float* lsew,
+                            void* dqkv, float* dbias_t, int B, int H, int W, int C, int heads, int ws,
+                            int shift, int dtype, sodt_stream_t st);
+
 /* Front end (backbone_vit.py:195-210): channel split, 4x Conv2d(1->48,k4,s4) (R with
  * padding 1), pairwise cross-channel attention (R<-G, G<-B, B<-IR, IR<-G; 12 heads x 4,
  * scale 1/2, window ca_ws, no projections) + residual + LayerNorm(48), concatenated to

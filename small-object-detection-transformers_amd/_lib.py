@@ -73,6 +73,9 @@ SIGNATURES = {
     "sodt_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "sodt_window_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sodt_window_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sodt_wmsa_pack": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sodt_wmsa_block_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sodt_window_attn_bwd_wm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sodt_frontend_fwd": [_P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sodt_frontend_bwd": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sodt_patch_embed4_fwd": [_P, _P, _L, _P, _P, _P, _I, _I, _P],
@@ -113,6 +116,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.sodt_wmsa_pack_bytes.argtypes = [_I, _I, _I, _I]
+    lib.sodt_wmsa_pack_bytes.restype = C.c_long
     lib.sodt_version.restype = C.c_char_p
     lib.sodt_version.argtypes = []
     _lib = lib
@@ -120,4 +125,4 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGNATURES.keys()) + ["sodt_version"]
+    return list(SIGNATURES.keys()) + ["sodt_version", "sodt_wmsa_pack_bytes"]

@@ -1078,7 +1078,9 @@ template <> __device__ __forceinline__ uint4 fragTp<float>(const unsigned char* 
   return fragT<float>(tile, rowbytes, 16 * kbq, col0, lane);
 }
 
-template <typename T, int HD, int NW>
+// WM: q / k / v and the log-sum-exp come in the WINDOW-MAJOR layout the fused forward (wmsa_block.hip) saves:
+// qkv = [window][head][q|k|v][64 tokens][HD], lse = [window][head][64] - 2 KB contiguous per tensor, window and head.
+template <typename T, int HD, int NW, bool WM = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
                                                                 const T* __restrict__ d_out, const float* __restrict__ lse,
                                                                 T* __restrict__ dqkv, float* __restrict__ dbias_t,
@@ -1137,18 +1139,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
     const int r = idx / CPR, cc = idx - r * CPR;                                        \
     int row, rid, iy, ix;                                                               \
     win_token(g, b_, wy_, wx_, r, row, rid, iy, ix);                                    \
-    const T* src = qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL;                    \
-    pq##i = *(const uint4*)(src); pk##i = *(const uint4*)(src + g.C); pv##i = *(const uint4*)(src + 2 * g.C); \
+    if constexpr (WM) {                                                                 \
+      const int h_ = cc / L::DCH, dc_ = cc - h_ * L::DCH;                               \
+      const T* src = qkv + (((long)(ITEM) * g.heads + hg * NW + h_) * 3 * 64 + r) * HD + dc_ * KPL; \
+      pq##i = *(const uint4*)(src); pk##i = *(const uint4*)(src + 64 * HD); pv##i = *(const uint4*)(src + 2 * 64 * HD); \
+    } else {                                                                            \
+      const T* src = qkv + (long)row * C3 + (hg * NW) * HD + cc * KPL;                  \
+      pq##i = *(const uint4*)(src); pk##i = *(const uint4*)(src + g.C); pv##i = *(const uint4*)(src + 2 * g.C); \
+    }                                                                                   \
     pd##i = *(const uint4*)(d_out + (long)row * g.C + (hg * NW) * HD + cc * KPL);       \
   }
 #define B2_ISSUE(ITEM) {                                                                \
     B2_ISSUE_ONE(0, ITEM) B2_ISSUE_ONE(1, ITEM) B2_ISSUE_ONE(2, ITEM) B2_ISSUE_ONE(3, ITEM) \
-    int t2_ = (ITEM);                                                                   \
-    const int wx2_ = t2_ % g.nwx; t2_ /= g.nwx;                                         \
-    const int wy2_ = t2_ % g.nwy; const int b2_ = t2_ / g.nwy;                          \
-    int row2, rid2, iy2, ix2;                                                           \
-    win_token(g, b2_, wy2_, wx2_, lane, row2, rid2, iy2, ix2);                          \
-    plse = lse[(long)row2 * g.heads + head];                                            \
+    if constexpr (WM) {                                                                 \
+      plse = lse[((long)(ITEM) * g.heads + head) * 64 + lane];                          \
+    } else {                                                                            \
+      int t2_ = (ITEM);                                                                 \
+      const int wx2_ = t2_ % g.nwx; t2_ /= g.nwx;                                       \
+      const int wy2_ = t2_ % g.nwy; const int b2_ = t2_ / g.nwy;                        \
+      int row2, rid2, iy2, ix2;                                                         \
+      win_token(g, b2_, wy2_, wx2_, lane, row2, rid2, iy2, ix2);                        \
+      plse = lse[(long)row2 * g.heads + head];                                          \
+    }                                                                                   \
   }
 #define B2_STORE_ONE(i)                                                                 \
   if constexpr (NPF > i) {                                                              \
@@ -1638,6 +1650,17 @@ int launch_fwd(const void* qkv, const float* bias_t, void* out, float* lse, cons
 }
 
 template <typename T, int HD, int NW>
+int launch_bwd_wm(const void* qkvw, const float* bias_t, const void* dout, const float* lsew, void* dqkv,
+                  float* dbias_t, const AttnGeo& g, hipStream_t st) {
+  if (g.heads % NW || g.nqt != 1 || g.ws != 8) return SODT_EINVAL;
+  const int nwin = g.B * g.nwy * g.nwx;
+  const int gx = nwin < 1024 ? nwin : 1024;
+  hipLaunchKernelGGL((attn_bwd_fast2_kernel<T, HD, NW, true>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
+                     (const T*)qkvw, bias_t, (const T*)dout, lsew, (T*)dqkv, dbias_t, g, nwin);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+template <typename T, int HD, int NW>
 int launch_bwd(const void* qkv, const float* bias_t, const void* out, const void* dout, const float* lse, void* dqkv,
                float* dbias_t, float* scratch, const AttnGeo& g, hipStream_t st) {
   if (g.heads % NW) return SODT_EINVAL;
@@ -1729,5 +1752,19 @@ extern "C" int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const 
     if (hd == 32) return launch_bwd<float, 32, 2>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
     if (hd == 64) return launch_bwd<float, 64, 1>(qkv, bias_t, out, dout, lse, dqkv, dbias_t, dq_acc, g, st);
   }
+  return SODT_EINVAL;
+}
+
+/* the same backward on the window-major q / k / v and log-sum-exp the fused forward saves (wmsa_block.hip) */
+extern "C" int sodt_window_attn_bwd_wm(const void* qkvw, const float* bias_t, const void* dout, const float* lsew,
+                                       void* dqkv, float* dbias_t, int B, int H, int W, int C, int heads, int ws,
+                                       int shift, int dtype, sodt_stream_t st_) {
+  AttnGeo g;
+  if (!qkvw || !bias_t || !dout || !lsew || !dqkv || !dbias_t || !make_geo(g, B, H, W, C, heads, ws, shift)) return SODT_EINVAL;
+  hipStream_t st = (hipStream_t)st_;
+  const int hd = C / heads;
+  if (hd != 16) return SODT_EINVAL;
+  if (dtype == SODT_BF16) return launch_bwd_wm<bf16, 16, 4>(qkvw, bias_t, dout, lsew, dqkv, dbias_t, g, st);
+  if (dtype == SODT_F32) return launch_bwd_wm<float, 16, 2>(qkvw, bias_t, dout, lsew, dqkv, dbias_t, g, st);
   return SODT_EINVAL;
 }

@@ -1,0 +1,591 @@
+// Fused W-MSA / SW-MSA half of a Swin block for gfx950: one launch computes
+//
+//     x_mid = x + Proj( WindowAttention( LN1(x) ) )          backbone_vit.py:1088-1126, :961-992
+//     xn2   = LN2(x_mid)                                     backbone_vit.py:1128 (the MLP's input)
+//
+// for C = 192 (12 heads x 16), 8x8 windows, shift 0 or s (stage 1 of model.yaml: backbone_vit.py:117-133).  The input
+// is read once and x_mid / xn2 are written once; LayerNorm, the QKV projection, q k^T, relative-position bias, the
+// -100 shift mask, softmax, p v, the output projection, bias, residual and the second LayerNorm never touch HBM.
+// roll / window_partition / window_unpartition / roll back (:1094-1124, :619-672) are index arithmetic on the global
+// loads and stores.  Training additionally writes what the hand-written backward needs (LN1 output, LN statistics,
+// q / k / v, log-sum-exp, attention output): see "saved tensors" below.
+//
+// Work decomposition (wave64, one workgroup per CU, persistent over windows):
+//   * ONE WAVE OWNS ONE WINDOW (64 tokens) end to end, so the whole chain is wave-local: no workgroup barrier orders
+//     any data flow inside a window.  A workgroup is NWV such waves (4 for bf16, 2 for f32).
+//   * The weights (Wqkv 221 KB + Wproj 74 KB in bf16: more than the 160 KB of LDS) are streamed per HEAD: stage h =
+//     {Wq_h, Wk_h, Wv_h (48 x 192), Wproj[:, h] (192 x 16), the head's relative-position bias table, its q/k/v
+//     bias} = 26 KB, double-buffered in LDS and shared by the NWV windows, i.e. every weight byte crosses
+//     L2 -> LDS once per 256 token rows.  The only workgroup barrier is the stage hand-over, once per head.
+//     Stages are copied global -> registers -> LDS by all threads while the previous head computes (plain loads:
+//     the compiler's own vmcnt bookkeeping keeps them in flight; side-output stores issued later do not delay them).
+//   * LN1(x) of the wave's window stays in LDS ([64][192], XOR-swizzled 16-byte chunks: every fragment read is
+//     conflict-free) and is the B operand of q^T = Wq xn^T, k^T = Wk xn^T and the A operand of v = xn Wv^T.
+//   * Operand chaining without LDS: the 16x16 accumulator of a TRANSPOSED product holds four consecutive channels
+//     of one token per lane, which is exactly the k16 operand layout (lane (g, t): k = 4 g + j) of the next MFMA:
+//         q^T, k^T accumulators        -> A / B operands of S^T = K Q^T            (v_mfma_f32_16x16x16_bf16)
+//         v accumulators (4 tokens of one channel per lane) and P^T = softmax(S^T) -> A / B operands of O^T = V^T P^T
+//         O^T accumulators             -> B operand of out^T += Wproj[:, h] O^T    (accumulated over the 12 heads in
+//                                         48 accumulator tiles = 192 VGPRs; one wave per SIMD, 512-register budget)
+//     The softmax of a query is 16 in-lane values + two cross-group shuffles; 1 / sum is an in-lane scalar of O^T.
+//   * Relative-position bias: for 8x8 windows the table entry of (query, key) depends on the 16-token strips only
+//     through their difference, so a lane needs 7 x 4 values per head; the stage carries the head's table x log2 e in
+//     four 0..3-element-shifted copies so that each group of four is ONE aligned LDS read.
+//   * Epilogue: out^T + bias goes through the wave's (now dead) LN1 tile in f32, is read back token-major together
+//     with x (coalesced 16-byte chunks), LN2 is computed in registers, x_mid and xn2 leave as 16-byte stores.
+//
+// Saved tensors (training; all written with full-line coalesced stores from registers, v through a 2 KB patch):
+//   xn1 [M][C], ao [M][C] natural token order (operands of the dWqkv / dWproj GEMMs), st1 / st2 [M][2] f32,
+//   qkvw [window][head][q|k|v][64 tokens][16]  and  lsew [window][head][64]  in WINDOW-MAJOR order (window =
+//   (b * nwy + wy) * nwx + wx after the cyclic shift, token = window-local row-major): the layout the attention
+//   backward stages into LDS anyway (sodt_window_attn_bwd_wm), 6 KB contiguous per (window, head).
+#include "common.h"
+#include "../../include/sodt_hip.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int WC = 192, WHD = 16, WHEADS = 12, WWS = 8;
+#define WMSA_LOG2E 1.4426950408889634f
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_;
+
+template <typename T> struct WL {
+  static constexpr int E = TT<T>::SZ, KPL = TT<T>::KPL, KU = TT<T>::MMA_K;
+  static constexpr int KSTEPS = WC / KU;                 // 6 (bf16) / 12 (f32) MFMA k-steps over the channels
+  static constexpr int ROWB = WC * E;                    // bytes of a token row: 384 / 768
+  static constexpr int NCH = ROWB / 16;                  // 16-byte chunks per row: 24 / 48
+  static constexpr int CHL = NCH / 4;                    // chunks per lane and token in the (g, t) mapping: 6 / 12
+  static constexpr int K16B = 4 * E;                     // bytes of a k16 operand per lane: 8 / 16
+  static constexpr int WFRAG = KSTEPS * 1024;            // Wq_h (or Wk_h, Wv_h) in fragment order: 6 KB / 12 KB
+  static constexpr int WQ_OFF = 0, WK_OFF = WFRAG, WV_OFF = 2 * WFRAG, WP_OFF = 3 * WFRAG;
+  static constexpr int WPB = WHEADS * 64 * K16B;         // Wproj[:, h] as 12 n-strips of k16 operands: 6 KB / 12 KB
+  static constexpr int BIAS_OFF = WP_OFF + WPB;
+  static constexpr int BIASB = 4 * 15 * 16 * E;          // four shifted copies of the head's [15][16] table (x log2 e)
+  static constexpr int BQKV_OFF = BIAS_OFF + BIASB;      // bq[16] bk[16] bv[16] f32, padded to 256 bytes
+  static constexpr int STAGE = BQKV_OFF + 256;           // 26752 / 53248 bytes
+  static constexpr int TAIL_OFF = WHEADS * STAGE;        // bproj[192], g1, b1, g2, b2: f32
+  static constexpr int PACK_BYTES = TAIL_OFF + 5 * WC * 4;
+  static constexpr int XNB = 64 * ROWB;                  // one wave's LN1 tile: 24 KB / 48 KB
+  static constexpr int VPB = 64 * WHD * E;               // v transposition patch: 2 KB / 4 KB
+  static constexpr int PASSES = (64 * WC * 4) / XNB;     // epilogue passes through the tile in f32: 2 / 1
+};
+static_assert(WL<bf16>::STAGE == 26752 && WL<float>::STAGE == 53248, "stage layout");
+
+struct WArgs {
+  const unsigned char* x; const unsigned char* wpk;
+  unsigned char* xm; unsigned char* xn2; float* st1; float* st2;
+  unsigned char* xn1; unsigned char* qkvw; float* lsew; unsigned char* ao;
+  int B, H, W, shift, nwy, nwx, nwin;
+};
+
+// ---- k16 operands: 16 contraction elements per MFMA, lane (g, t) holds k = 4 g + j, j = 0..3
+template <typename T> struct K16;
+template <> struct K16<bf16> { typedef uint2 type; };
+template <> struct K16<float> { typedef uint4 type; };
+
+template <typename T> __device__ __forceinline__ typename K16<T>::type pk16(const f32x4& v);
+template <> __device__ __forceinline__ uint2 pk16<bf16>(const f32x4& v) { return make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])); }
+template <> __device__ __forceinline__ uint4 pk16<float>(const f32x4& v) {
+  return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+__device__ __forceinline__ void mmak16(f32x4& acc, const uint2& a, const uint2& b) {      // v_mfma_f32_16x16x16_bf16
+  union { uint2 u; s16x4_ v; } ua, ub;
+  ua.u = a; ub.u = b;
+  acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ua.v, ub.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mmak16(f32x4& acc, const uint4& a, const uint4& b) { mma16<float>(acc, a, b); }
+
+// wave-private LDS hand-over between lanes of ONE wave: LDS operations of a wave execute in order, so only the
+// compiler has to be told (no s_barrier)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// token row (natural order) of window-local token n of window (b, wy, wx) after the cyclic shift (backbone_vit.py:1096)
+__device__ __forceinline__ int wtoken(const WArgs& a, int b, int wy, int wx, int n) {
+  int y = wy * WWS + (n >> 3) + a.shift, x = wx * WWS + (n & 7) + a.shift;
+  if (y >= a.H) y -= a.H;
+  if (x >= a.W) x -= a.W;
+  return (b * a.H + y) * a.W + x;
+}
+// mask region of a token in the shifted frame (backbone_vit.py:1061-1072)
+__device__ __forceinline__ int wrid(const WArgs& a, int wy, int wx, int n) {
+  const int ys = wy * WWS + (n >> 3), xs = wx * WWS + (n & 7);
+  const int ry = ys < a.H - WWS ? 0 : (ys < a.H - a.shift ? 1 : 2);
+  const int rx = xs < a.W - WWS ? 0 : (xs < a.W - a.shift ? 1 : 2);
+  return ry * 3 + rx;
+}
+
+template <typename T, int NWV, int NST>
+__global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) {
+  using L = WL<T>;
+  constexpr int E = L::E, KPL = L::KPL, NT = NWV * 64;
+  constexpr int NCHK = L::STAGE / 16;                    // 16-byte chunks per stage
+  constexpr int NPF = (NCHK + NT - 1) / NT;              // per thread: 7 (bf16, 256 threads) / 26 (f32, 128 threads)
+  typedef typename K16<T>::type k16_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // smem: LN1 tiles [NWV][64][ROWB] | stages [NST][STAGE] | v patches [NWV][64][16]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = lane & 15, g = lane >> 4;
+  // LDS byte offsets as  per-lane base (one VGPR) + compile-time immediate.  LN1 tile: chunk c = 4 k + g of token row
+  // r = 16 ms + t sits at chunk c ^ (r & 7) = 4 (k ^ b) + (g ^ (t & 3)), b = bit 2 of t: even k moves by +64 b bytes,
+  // odd k by -64 b, so two bases serve every (ms, k).
+  constexpr unsigned SST0 = NWV * L::XNB, SVP0 = SST0 + NST * L::STAGE;
+  const unsigned xnb = (unsigned)(w * L::XNB);
+  const unsigned gx3 = (unsigned)((g ^ (t & 3)) << 4);
+  const unsigned xrow = xnb + (unsigned)(t * L::ROWB) + gx3, swb = (unsigned)(((t >> 2) & 1) * 64);
+  const unsigned xfE = xrow + swb, xfO = xrow - swb;
+#define XN_ADDR(ms, k) ((((k) & 1) ? xfO : xfE) + (unsigned)((ms) * 16 * L::ROWB + 64 * (k)))
+  // the same tile as the epilogue's f32 staging area [tokens][192] f32: chunk c4 of row r at c4 ^ (r & 3)
+  const unsigned strow = xnb + (unsigned)(t * WC * 4) + gx3;
+  const unsigned l16 = (unsigned)(lane * 16), lk16 = (unsigned)(lane * L::K16B);
+  const unsigned vpw = SVP0 + (unsigned)(w * L::VPB) + (unsigned)((4 * g * WHD + t) * E);   // + (16 ms + r) * WHD * E
+  const unsigned vpr = SVP0 + (unsigned)(w * L::VPB) + l16;
+  const bool save = a.xn1 != nullptr;
+  const unsigned char* tail = a.wpk + L::TAIL_OFF;       // f32: bproj | g1 | b1 | g2 | b2; read with 32-bit lane offsets
+  const unsigned goff = (unsigned)(g * KPL * 4);         // byte offset of this lane's first channel inside a 4-chunk group
+  const float scale2 = 0.25f * WMSA_LOG2E;               // hd^-1/2 x log2 e
+
+  // ---- stage copy.  Double-buffered (bf16): global -> registers (in flight while a head computes) -> LDS; the loads are
+  // unconditional so that the slots stay registers (the chunks past STAGE belong to the next head / the tail of the
+  // pack buffer and are simply not written to LDS).  Single-buffered (f32 parity path): a plain copy loop between two
+  // barriers.
+  static_assert(NST == 1 || NPF == 7, "seven prefetch slots");
+  static_assert(NST == 1 || (WHEADS - 1) * L::STAGE + NPF * NT * 16 <= L::PACK_BYTES, "prefetch overrun stays inside the pack buffer");
+  uint4 pf0, pf1, pf2, pf3, pf4, pf5, pf6;                // individual registers: hipcc leaves an array of them in scratch
+#define PF_ISSUE(HEAD)                                                                  \
+  if constexpr (NST == 2) {                                                             \
+    const uint4* src_ = (const uint4*)(a.wpk + (unsigned)((HEAD) * L::STAGE)) + tid;    \
+    pf0 = src_[0]; pf1 = src_[NT]; pf2 = src_[2 * NT]; pf3 = src_[3 * NT];              \
+    pf4 = src_[4 * NT]; pf5 = src_[5 * NT]; pf6 = src_[6 * NT];                         \
+  }
+#define PF_STORE(BUF, HEAD)                                                             \
+  if constexpr (NST == 2) {                                                             \
+    uint4* dst_ = (uint4*)(smem + SST0 + (unsigned)((BUF) * L::STAGE)) + tid;           \
+    dst_[0] = pf0; dst_[NT] = pf1; dst_[2 * NT] = pf2; dst_[3 * NT] = pf3;              \
+    dst_[4 * NT] = pf4; dst_[5 * NT] = pf5;                                             \
+    if (tid + 6 * NT < NCHK) dst_[6 * NT] = pf6;                                        \
+  } else {                                                                              \
+    const uint4* src_ = (const uint4*)(a.wpk + (unsigned)((HEAD) * L::STAGE));          \
+    uint4* dst_ = (uint4*)(smem + SST0);                                                \
+    for (int idx_ = tid; idx_ < NCHK; idx_ += NT) dst_[idx_] = src_[idx_];              \
+  }
+  PF_ISSUE(0)
+  PF_STORE(0, 0)
+  int sidx = 0;
+
+  // bias-table addressing of this lane (see the header): four consecutive entries r = 0..3 at one aligned address
+  const int j0 = 7 - (t & 7) + 4 * (g & 1), jv = j0 & 3;
+  const int bias_lane_off = L::BIAS_OFF + (((jv * 15 + (t >> 3) - (g >> 1) + 7) * 16) + (j0 - jv)) * E;   // strip difference 0
+
+  const int nquads = (a.nwin + NWV - 1) / NWV;
+  for (int it = blockIdx.x; it < nquads; it += gridDim.x) {
+    int item = it * NWV + w;
+    const bool valid = item < a.nwin;
+    if (!valid) item = a.nwin - 1;
+    int tq = item;
+    const int wx = tq % a.nwx; tq /= a.nwx;
+    const int wy = tq % a.nwy; const int b = tq / a.nwy;
+    const bool msk = a.shift > 0 && (wy == a.nwy - 1 || wx == a.nwx - 1);
+    // every global access of the window is  uniform base + 32-bit byte offset (+ immediate): one VGPR per token strip
+    // (row * ROWB < 2^31 is checked on the host), not a 64-bit pointer per access held across the head loop
+    unsigned rows[4], roff[4];
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      rows[ms] = (unsigned)wtoken(a, b, wy, wx, 16 * ms + t);
+      roff[ms] = rows[ms] * (unsigned)L::ROWB + (unsigned)(g * 16);
+    }
+    const unsigned whoff = (unsigned)item * WHEADS;       // (window, head 0) index of the window-major tensors
+    // bit (4 ks + r) of diffm[ms]: query (ms, t) and key (ks, 4 g + r) lie in different mask regions
+    unsigned diffm[4] = {0u, 0u, 0u, 0u};
+    if (msk) {
+      int kr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) kr[i] = wrid(a, wy, wx, 16 * (i >> 2) + 4 * g + (i & 3));
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        const int qr = wrid(a, wy, wx, 16 * ms + t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) diffm[ms] |= (qr != kr[i] ? 1u : 0u) << i;
+      }
+    }
+
+    // ================= prologue: LN1 of the window -> LDS tile (and xn1 / st1 when saving)
+    {
+      uint4 xc[4][L::CHL];
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+        for (int i = 0; i < L::CHL; ++i) xc[ms][i] = *(const uint4*)(a.x + (roff[ms] + 64u * i));
+      float mean[4], rstd[4];
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < L::CHL; ++i) {
+          float f[KPL];
+          unpack<T>(xc[ms][i], f);
+#pragma unroll
+          for (int j = 0; j < KPL; ++j) s += f[j];
+        }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mu = s * (1.0f / WC);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < L::CHL; ++i) {
+          float f[KPL];
+          unpack<T>(xc[ms][i], f);
+#pragma unroll
+          for (int j = 0; j < KPL; ++j) { const float d = f[j] - mu; q = fmaf(d, d, q); }
+        }
+        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+        mean[ms] = mu;
+        rstd[ms] = rsqrtf(q * (1.0f / WC) + 1e-5f);
+        if (save && valid && g == 0) *(float2*)((unsigned char*)a.st1 + rows[ms] * 8u) = make_float2(mu, rstd[ms]);
+      }
+      wave_sync();                                       // the previous window's epilogue is done with the tile
+#pragma unroll
+      for (int i = 0; i < L::CHL; ++i) {
+        const int c = 4 * i + g;
+        float ga[KPL], be[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; j += 4) {
+          *(float4*)(ga + j) = *(const float4*)(tail + (goff + (unsigned)((WC + 4 * i * KPL + j) * 4)));
+          *(float4*)(be + j) = *(const float4*)(tail + (goff + (unsigned)((2 * WC + 4 * i * KPL + j) * 4)));
+        }
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          float f[KPL];
+          unpack<T>(xc[ms][i], f);
+#pragma unroll
+          for (int j = 0; j < KPL; ++j) f[j] = fmaf((f[j] - mean[ms]) * rstd[ms], ga[j], be[j]);
+          const uint4 y = pack<T>(f);
+          *(uint4*)(smem + XN_ADDR(ms, i)) = y;
+          if (save && valid) *(uint4*)(a.xn1 + (roff[ms] + 64u * i)) = y;
+        }
+      }
+      wave_sync();
+    }
+
+    // ================= the 12 heads
+    f32x4 outT[WHEADS][4];                               // out^T: [n strip][token strip], row = channel 16 n + 4 g + r, column = token t
+#pragma unroll
+    for (int n = 0; n < WHEADS; ++n)
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) outT[n][ms] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int h = 0; h < WHEADS; ++h) {
+      const int buf = NST == 2 ? (sidx & 1) : 0;
+      __syncthreads();                                   // stage `buf` is complete; everyone has left the other buffer
+      const unsigned sbo = SST0 + (unsigned)(buf * L::STAGE);      // this head's stage
+      const unsigned wb16 = sbo + l16, wbk = sbo + L::WP_OFF + lk16, bb = sbo + (unsigned)bias_lane_off;
+      const int hnext = h + 1 == WHEADS ? 0 : h + 1;
+      PF_ISSUE(hnext)
+
+      auto body = [&](auto MSK_) {
+        constexpr bool MSK = decltype(MSK_)::value;
+        // ---- q^T, k^T (channel rows, token columns) and v (token rows, channel columns) of this head
+        f32x4 qT[4], kT[4], vv[4];
+        {
+          const unsigned bqo = sbo + L::BQKV_OFF;
+          const f32x4 bqv = *(const f32x4*)(smem + (bqo + (unsigned)(16 * g))), bkv = *(const f32x4*)(smem + (bqo + (unsigned)(64 + 16 * g)));
+          const float bvs = *(const float*)(smem + (bqo + (unsigned)(128 + 4 * t)));
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) { qT[ms] = bqv; kT[ms] = bkv; vv[ms] = f32x4{bvs, bvs, bvs, bvs}; }
+        }
+#pragma unroll
+        for (int kk = 0; kk < L::KSTEPS; ++kk) {
+          const uint4 wq = *(const uint4*)(smem + (wb16 + (unsigned)(L::WQ_OFF + kk * 1024)));
+          const uint4 wk = *(const uint4*)(smem + (wb16 + (unsigned)(L::WK_OFF + kk * 1024)));
+          const uint4 wv = *(const uint4*)(smem + (wb16 + (unsigned)(L::WV_OFF + kk * 1024)));
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) {
+            const uint4 xf = *(const uint4*)(smem + XN_ADDR(ms, kk));
+            mma16<T>(qT[ms], wq, xf);
+            mma16<T>(kT[ms], wk, xf);
+            mma16<T>(vv[ms], xf, wv);
+          }
+        }
+        k16_t pq[4], pkk[4], pv[4];
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) { pq[ms] = pk16<T>(qT[ms]); pkk[ms] = pk16<T>(kT[ms]); pv[ms] = pk16<T>(vv[ms]); }
+        if (save && valid) {
+          unsigned char* qb = a.qkvw + (size_t)(whoff + h) * (3 * 64 * WHD * E);     // uniform
+          const unsigned lo = (unsigned)(t * (WHD * E) + g * L::K16B);
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) {
+            *(k16_t*)(qb + (lo + (unsigned)(16 * ms * WHD * E))) = pq[ms];
+            *(k16_t*)(qb + (lo + (unsigned)(64 * WHD * E + 16 * ms * WHD * E))) = pkk[ms];
+          }
+          // v: [token][16] through the patch (the accumulator holds four tokens of ONE channel per lane)
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *(T*)(smem + (vpw + (unsigned)((16 * ms + r) * WHD * E))) = from_f<T>(vv[ms][r]);
+          wave_sync();
+#pragma unroll
+          for (int i = 0; i < L::VPB / 1024; ++i)
+            *(uint4*)(qb + (unsigned)(2 * 64 * WHD * E + (i * 64 + lane) * 16)) = *(const uint4*)(smem + (vpr + (unsigned)(i * 1024)));
+          wave_sync();
+        }
+        // ---- S^T = K Q^T: row = key 16 ks + 4 g + r, column = query 16 ms + t; softmax per query
+        f32x4 bia[7];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) {
+          const unsigned char* p = smem + ((bb - (unsigned)(3 * 2 * 16 * E)) + (unsigned)(d * 2 * 16 * E));   // strip difference d - 3
+          if constexpr (std::is_same<T, bf16>::value) {
+            const uint2 u = *(const uint2*)p;
+            bia[d] = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u)};
+          } else {
+            bia[d] = *(const f32x4*)p;
+          }
+        }
+        k16_t pp[4][4];                                  // P^T strips, packed: [ks][ms]
+        float inv[4];
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          f32x4 s[4];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) { s[ks] = f32x4{0.f, 0.f, 0.f, 0.f}; mmak16(s[ks], pkk[ks], pq[ms]); }
+          float mx = -1e30f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = fmaf(s[ks][r], scale2, bia[ms - ks + 3][r]);
+              if constexpr (MSK) { if ((diffm[ms] >> (4 * ks + r)) & 1u) v += -100.0f * WMSA_LOG2E; }
+              s[ks][r] = v;
+              mx = fmaxf(mx, v);
+            }
+          mx = fmaxf(mx, __shfl_xor(mx, 16));
+          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          float sum = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(s[ks][r] - mx); s[ks][r] = p; sum += p; }
+            pp[ks][ms] = pk16<T>(s[ks]);
+          }
+          sum += __shfl_xor(sum, 16);
+          sum += __shfl_xor(sum, 32);
+          inv[ms] = __builtin_amdgcn_rcpf(sum);
+          if (save && valid && g == 0)
+            (a.lsew + (size_t)(whoff + h) * 64)[16 * ms + t] = mx * (1.0f / WMSA_LOG2E) + __logf(sum);
+        }
+        // ---- O^T = V^T P^T: row = channel 4 g + r, column = query; then out^T += Wproj[:, h] O^T
+        k16_t po[4];
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (std::is_same<T, bf16>::value) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp)
+              mma16<bf16>(o, make_uint4(pv[2 * kp].x, pv[2 * kp].y, pv[2 * kp + 1].x, pv[2 * kp + 1].y),
+                          make_uint4(pp[2 * kp][ms].x, pp[2 * kp][ms].y, pp[2 * kp + 1][ms].x, pp[2 * kp + 1][ms].y));
+          } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) mmak16(o, pv[ks], pp[ks][ms]);
+          }
+          o *= inv[ms];
+          po[ms] = pk16<T>(o);
+          if (save && valid) *(k16_t*)(a.ao + (size_t)(WHD * h * E) + (roff[ms] - (unsigned)(g * (16 - L::K16B)))) = po[ms];
+        }
+#pragma unroll
+        for (int n = 0; n < WHEADS; ++n) {
+          const k16_t wp = *(const k16_t*)(smem + (wbk + (unsigned)(n * 64 * L::K16B)));
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) mmak16(outT[n][ms], wp, po[ms]);
+        }
+      };
+      if (msk) body(std::true_type{}); else body(std::false_type{});
+
+      if (NST == 1) __syncthreads();                     // single buffer: everyone is done reading before it is refilled
+      PF_STORE(NST == 2 ? (buf ^ 1) : 0, hnext)
+      ++sidx;
+    }
+
+    // ================= epilogue: x_mid = x + out + bproj, xn2 = LN2(x_mid)
+    constexpr int MSP = 4 / L::PASSES;                   // token strips per pass through the (f32) tile
+#pragma unroll
+    for (int ps = 0; ps < L::PASSES; ++ps) {
+      wave_sync();
+#pragma unroll
+      for (int ml = 0; ml < MSP; ++ml) {
+        const int ms = ps * MSP + ml;
+#pragma unroll
+        for (int n = 0; n < WHEADS; ++n) {
+          const f32x4 bp = *(const f32x4*)(tail + ((unsigned)(g * 16) + (unsigned)(64 * n)));
+          *(f32x4*)(smem + (strow + (unsigned)(ml * 16 * WC * 4 + 64 * n))) = outT[n][ms] + bp;     // chunk (4 n + g) ^ (t & 3)
+        }
+      }
+      wave_sync();
+#pragma unroll
+      for (int ml = 0; ml < MSP; ++ml) {
+        const int ms = ps * MSP + ml;
+        float v[L::CHL][KPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < L::CHL; ++i) {
+          float f[KPL];
+          unpack<T>(*(const uint4*)(a.x + (roff[ms] + 64u * i)), f);
+#pragma unroll
+          for (int j = 0; j < KPL; j += 4) {
+            // f32 chunk c4 = (c KPL + j) / 4 of channels c KPL + j .. + 3, stored at c4 ^ (t & 3)
+            const unsigned lowc = (unsigned)((((g * KPL + j) >> 2) & 3) ^ (t & 3)), hic = (unsigned)(((g * KPL + j) >> 2) >> 2);
+            const f32x4 o = *(const f32x4*)(smem + (xnb + (unsigned)(t * WC * 4) + ((hic * 4 + lowc) << 4) +
+                                                    (unsigned)(ml * 16 * WC * 4 + i * KPL * 16)));
+            // x_mid is stored in T: LN2 normalises the ROUNDED value, exactly as a separate LayerNorm launch reading x_mid
+            // would (and as the LayerNorm backward, which re-reads x_mid, assumes)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) v[i][j + q4] = to_f(from_f<T>(f[j + q4] + o[q4]));
+          }
+#pragma unroll
+          for (int j = 0; j < KPL; ++j) s += v[i][j];
+        }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mu = s * (1.0f / WC);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < L::CHL; ++i)
+#pragma unroll
+          for (int j = 0; j < KPL; ++j) { const float d = v[i][j] - mu; q = fmaf(d, d, q); }
+        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+        const float rs = rsqrtf(q * (1.0f / WC) + 1e-5f);
+        if (valid) {
+          if (save && g == 0) *(float2*)((unsigned char*)a.st2 + rows[ms] * 8u) = make_float2(mu, rs);
+#pragma unroll
+          for (int i = 0; i < L::CHL; ++i) {
+            const int c = 4 * i + g;
+            const uint4 xmv = pack<T>(v[i]);
+            *(uint4*)(a.xm + (roff[ms] + 64u * i)) = xmv;
+            float f[KPL], ga[KPL], be[KPL];
+#pragma unroll
+            for (int j = 0; j < KPL; j += 4) {
+              *(float4*)(ga + j) = *(const float4*)(tail + (goff + (unsigned)((3 * WC + 4 * i * KPL + j) * 4)));
+              *(float4*)(be + j) = *(const float4*)(tail + (goff + (unsigned)((4 * WC + 4 * i * KPL + j) * 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) f[j] = fmaf((v[i][j] - mu) * rs, ga[j], be[j]);
+            *(uint4*)(a.xn2 + (roff[ms] + 64u * i)) = pack<T>(f);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- parameter packing: raw f32 parameters of one block -> the stage-ordered buffer above
+template <typename T>
+__global__ __launch_bounds__(256) void wmsa_pack_kernel(const float* __restrict__ qkv_w, const float* __restrict__ qkv_b,
+                                                       const float* __restrict__ proj_w, const float* __restrict__ proj_b,
+                                                       const float* __restrict__ table, const float* __restrict__ n1w,
+                                                       const float* __restrict__ n1b, const float* __restrict__ n2w,
+                                                       const float* __restrict__ n2b, unsigned char* __restrict__ wpk) {
+  using L = WL<T>;
+  constexpr int KPL = L::KPL, KU = L::KU;
+  const int h = blockIdx.x, tid = threadIdx.x;
+  if (h == WHEADS) {
+    float* tl = (float*)(wpk + L::TAIL_OFF);
+    for (int i = tid; i < WC; i += 256) {
+      tl[i] = proj_b[i]; tl[WC + i] = n1w[i]; tl[2 * WC + i] = n1b[i]; tl[3 * WC + i] = n2w[i]; tl[4 * WC + i] = n2b[i];
+    }
+    return;
+  }
+  unsigned char* sb = wpk + (long)h * L::STAGE;
+  // Wq_h / Wk_h / Wv_h in fragment order: [k-step][lane][KPL], lane (g, t) = row 16 h + t, columns KU kk + KPL g + j
+  for (int sect = 0; sect < 3; ++sect) {
+    T* dst = (T*)(sb + sect * L::WFRAG);
+    for (int e = tid; e < L::KSTEPS * 64 * KPL; e += 256) {
+      const int kk = e / (64 * KPL), l = (e / KPL) % 64, j = e % KPL;
+      dst[e] = from_f<T>(qkv_w[(long)(sect * WC + WHD * h + (l & 15)) * WC + KU * kk + KPL * (l >> 4) + j]);
+    }
+  }
+  // Wproj[:, 16 h .. 16 h + 15] as 12 n-strips of k16 operands: lane (g, t) = row 16 n + t, columns 16 h + 4 g + j
+  {
+    T* dst = (T*)(sb + L::WP_OFF);
+    for (int e = tid; e < WHEADS * 64 * 4; e += 256) {
+      const int n = e / 256, l = (e / 4) % 64, j = e % 4;
+      dst[e] = from_f<T>(proj_w[(long)(16 * n + (l & 15)) * WC + WHD * h + 4 * (l >> 4) + j]);
+    }
+  }
+  // relative-position bias of this head x log2 e: copy v, row dyi, position i holds table[dyi][14 - (i + v)]
+  {
+    T* dst = (T*)(sb + L::BIAS_OFF);
+    for (int e = tid; e < 4 * 15 * 16; e += 256) {
+      const int v = e / 240, dyi = (e / 16) % 15, i = e % 16, jj = i + v;
+      dst[e] = from_f<T>(jj <= 14 ? table[(dyi * 15 + (14 - jj)) * WHEADS + h] * WMSA_LOG2E : 0.f);
+    }
+  }
+  float* bq = (float*)(sb + L::BQKV_OFF);
+  for (int i = tid; i < 64; i += 256) bq[i] = i < 48 ? qkv_b[(i / 16) * WC + WHD * h + (i % 16)] : 0.f;
+}
+
+template <typename T, int NWV, int NST>
+int launch_block(const WArgs& a, hipStream_t st) {
+  using L = WL<T>;
+  constexpr int LDS = NWV * L::XNB + NST * L::STAGE + NWV * L::VPB;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  auto kern = wmsa_block_kernel<T, NWV, NST>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      (void)hipGetLastError();
+      return SODT_EINVAL;
+    }
+    attr_set = true;
+  }
+  const int nquads = (a.nwin + NWV - 1) / NWV;
+  const int grid = nquads < 256 ? nquads : 256;          // one workgroup per CU, persistent over the window groups
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), LDS, st, a);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+bool wmsa_shape_ok(int B, int H, int W, int C, int heads, int ws, int shift) {
+  return B > 0 && C == WC && heads == WHEADS && ws == WWS && H > 0 && W > 0 && H % WWS == 0 && W % WWS == 0 &&
+         shift >= 0 && shift < WWS && (long)B * H * W < (1L << 31) / (WC * 4);
+}
+
+}  // namespace
+
+extern "C" long sodt_wmsa_pack_bytes(int C, int heads, int ws, int dtype) {
+  if (C != WC || heads != WHEADS || ws != WWS) return 0;
+  return dtype == SODT_BF16 ? WL<bf16>::PACK_BYTES : (dtype == SODT_F32 ? WL<float>::PACK_BYTES : 0);
+}
+
+extern "C" int sodt_wmsa_pack(const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b,
+                              const float* rpb_table, const float* n1_w, const float* n1_b, const float* n2_w,
+                              const float* n2_b, void* wpk, int C, int heads, int ws, int dtype, sodt_stream_t st_) {
+  if (!qkv_w || !qkv_b || !proj_w || !proj_b || !rpb_table || !n1_w || !n1_b || !n2_w || !n2_b || !wpk) return SODT_EINVAL;
+  if (C != WC || heads != WHEADS || ws != WWS) return SODT_EINVAL;
+  hipStream_t st = (hipStream_t)st_;
+  if (dtype == SODT_BF16)
+    hipLaunchKernelGGL(wmsa_pack_kernel<bf16>, dim3(WHEADS + 1), dim3(256), 0, st, qkv_w, qkv_b, proj_w, proj_b, rpb_table,
+                       n1_w, n1_b, n2_w, n2_b, (unsigned char*)wpk);
+  else if (dtype == SODT_F32)
+    hipLaunchKernelGGL(wmsa_pack_kernel<float>, dim3(WHEADS + 1), dim3(256), 0, st, qkv_w, qkv_b, proj_w, proj_b, rpb_table,
+                       n1_w, n1_b, n2_w, n2_b, (unsigned char*)wpk);
+  else
+    return SODT_EINVAL;
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+extern "C" int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, void* xn2, float* st1, float* st2,
+                                   void* xn1, void* qkvw, float* lsew, void* ao,
+                                   int B, int H, int W, int C, int heads, int ws, int shift, int dtype, sodt_stream_t st_) {
+  if (!x || !wpk || !xm || !xn2 || !wmsa_shape_ok(B, H, W, C, heads, ws, shift)) return SODT_EINVAL;
+  const bool save = xn1 != nullptr;
+  if (save && (!qkvw || !lsew || !ao || !st1 || !st2)) return SODT_EINVAL;
+  WArgs a;
+  a.x = (const unsigned char*)x; a.wpk = (const unsigned char*)wpk;
+  a.xm = (unsigned char*)xm; a.xn2 = (unsigned char*)xn2; a.st1 = st1; a.st2 = st2;
+  a.xn1 = (unsigned char*)xn1; a.qkvw = (unsigned char*)qkvw; a.lsew = lsew; a.ao = (unsigned char*)ao;
+  a.B = B; a.H = H; a.W = W; a.shift = shift; a.nwy = H / WWS; a.nwx = W / WWS; a.nwin = B * a.nwy * a.nwx;
+  hipStream_t st = (hipStream_t)st_;
+  if (dtype == SODT_BF16) return launch_block<bf16, 4, 2>(a, st);
+  if (dtype == SODT_F32) return launch_block<float, 2, 1>(a, st);
+  return SODT_EINVAL;
+}

@@ -255,6 +255,27 @@ def window_attn_bwd(qkv, bias_t, out, dout, lse, dqkv, dbias_t, scratch, B, H, W
             B, H, W, Cc, heads, ws, shift, dt_code(qkv))
 
 
+def wmsa_pack_bytes(Cc: int, heads: int, ws: int, dtype_code: int) -> int:
+    """0 when the fused block kernel does not take this geometry (csrc/wmsa_block.hip: C 192, 12 heads, 8x8 windows)."""
+    return int(_lib.sodt_wmsa_pack_bytes(Cc, heads, ws, dtype_code))
+
+
+def wmsa_pack(qkv_w, qkv_b, proj_w, proj_b, table, n1w, n1b, n2w, n2b, wpk, Cc, heads, ws):
+    _launch("sodt_wmsa_pack", _p(qkv_w), _p(qkv_b), _p(proj_w), _p(proj_b), _p(table), _p(n1w), _p(n1b), _p(n2w), _p(n2b),
+            _p(wpk), Cc, heads, ws, L.BF16 if wpk.dtype == torch.bfloat16 else L.F32)
+
+
+def wmsa_block_fwd(x, wpk, xm, xn2, st1, st2, xn1, qkvw, lsew, ao, B, H, W, Cc, heads, ws, shift):
+    """x_mid = x + Proj(W-MSA(LN1 x)), xn2 = LN2(x_mid) in one launch; xn1 .. ao are the save-for-backward outputs (None: inference)."""
+    _launch("sodt_wmsa_block_fwd", _p(x), _p(wpk), _p(xm), _p(xn2), _p(st1), _p(st2), _p(xn1), _p(qkvw), _p(lsew), _p(ao),
+            B, H, W, Cc, heads, ws, shift, dt_code(x))
+
+
+def window_attn_bwd_wm(qkvw, bias_t, dout, lsew, dqkv, dbias_t, B, H, W, Cc, heads, ws, shift):
+    _launch("sodt_window_attn_bwd_wm", _p(qkvw), _p(bias_t), _p(dout), _p(lsew), _p(dqkv), _p(dbias_t),
+            B, H, W, Cc, heads, ws, shift, dt_code(dout))
+
+
 def frontend_fwd(rgb, ir_plane, ir_bstride, w, b, gamma, beta, out, B, S, ca_ws=1):
     _launch("sodt_frontend_fwd", _p(rgb), _p(ir_plane), ir_bstride, _p(w), _p(b), _p(gamma), _p(beta), _p(out),
             B, S, ca_ws, dt_code(out))

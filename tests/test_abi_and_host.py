@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def header_symbols():
     src = open(os.path.join(ROOT, "include", "sodt_hip.h")).read()
-    return sorted(set(re.findall(r"^(?:int|const char\*)\s+(sodt_\w+)\s*\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|long|const char\*)\s+(sodt_\w+)\s*\(", src, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol(pkg):
