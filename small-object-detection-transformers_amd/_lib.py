@@ -97,6 +97,7 @@ SIGNATURES = {
     "sodt_batch_sum": [_P, _P, _I, _L, _I, _P],
     "sodt_memset_zero": [_P, _L, _P],
     "sodt_gemm_set_variant": [_I],
+    "sodt_debug_wmsa_stamps": [_P, _I],
 }
 
 _lib = None

@@ -68,7 +68,6 @@ template <typename T> struct WL {
   static constexpr int PACK_BYTES = TAIL_OFF + 5 * WC * 4;
   static constexpr int XNB = 64 * ROWB;                  // one wave's LN1 tile: 24 KB / 48 KB
   static constexpr int VPB = 64 * WHD * E;               // v transposition patch: 2 KB / 4 KB
-  static constexpr int PASSES = (64 * WC * 4) / XNB;     // epilogue passes through the tile in f32: 2 / 1
 };
 static_assert(WL<bf16>::STAGE == 26752 && WL<float>::STAGE == 53248, "stage layout");
 
@@ -96,6 +95,71 @@ __device__ __forceinline__ void mmak16(f32x4& acc, const uint2& a, const uint2& 
 }
 __device__ __forceinline__ void mmak16(f32x4& acc, const uint4& a, const uint4& b) { mma16<float>(acc, a, b); }
 
+// ---- hand-scheduled LDS reads.  One wave per SIMD: nothing hides an LDS round trip but the wave's own MFMAs, and hipcc
+// places `s_waitcnt lgkmcnt(0)` right behind every read it can see.  The fragment reads of the hot loops are therefore
+// inline asm (invisible to the compiler's wait insertion), issued one k-step ahead, retired by counted waits whose
+// operand list ties the consuming MFMAs behind them.  LDS returns in order, so a compiler-generated wait can only
+// over-wait these reads, never miss them.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_;
+template <int OFF> __device__ __forceinline__ u32x4_ lds_rd128a(unsigned addr) {
+  u32x4_ v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ u32x2_ lds_rd64a(unsigned addr) {
+  u32x2_ v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ unsigned lds_rd32a(unsigned addr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <typename T> struct KR;                     // register image of a k16 operand / four table entries
+template <> struct KR<bf16> {
+  typedef u32x2_ type;
+  template <int OFF> static __device__ __forceinline__ type rd(unsigned a) { return lds_rd64a<OFF>(a); }
+  static __device__ __forceinline__ uint2 op(const type& v) { return make_uint2(v.x, v.y); }
+  static __device__ __forceinline__ type reg(const uint2& v) { return type{v.x, v.y}; }
+  static __device__ __forceinline__ f32x4 f4(const type& v) {
+    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+  }
+};
+template <> struct KR<float> {
+  typedef u32x4_ type;
+  template <int OFF> static __device__ __forceinline__ type rd(unsigned a) { return lds_rd128a<OFF>(a); }
+  static __device__ __forceinline__ uint4 op(const type& v) { return make_uint4(v.x, v.y, v.z, v.w); }
+  static __device__ __forceinline__ type reg(const uint4& v) { return type{v.x, v.y, v.z, v.w}; }
+  static __device__ __forceinline__ f32x4 f4(const type& v) {
+    return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+  }
+};
+__device__ __forceinline__ uint4 u4(const u32x4_& v) { return make_uint4(v.x, v.y, v.z, v.w); }
+#define LDS_DEP(x) asm volatile("" : "+v"(x))
+#define LAUNDER(p) asm volatile("" : "+v"(p))
+#define LDS_WAIT(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory")
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// reductions over the four 16-lane rows of the wave (lanes t, t + 16, t + 32, t + 48: one token / query held by the four
+// g groups): v_permlane32_swap + v_permlane16_swap on the VALU instead of two ds_bpermute round trips through the LDS
+// pipe (whose latency nothing hides at one wave per SIMD).  Every lane ends with the result.
+__device__ __forceinline__ float rows_sum(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows_max(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // wave-private LDS hand-over between lanes of ONE wave: LDS operations of a wave execute in order, so only the
 // compiler has to be told (no s_barrier)
 __device__ __forceinline__ void wave_sync() {
@@ -119,7 +183,16 @@ __device__ __forceinline__ int wrid(const WArgs& a, int wy, int wx, int n) {
   return ry * 3 + rx;
 }
 
-template <typename T, int NWV, int NST>
+// STAMP: diagnostic build (sodt_debug_wmsa_stamps): wave 0 of every workgroup sums shader cycles per phase
+__device__ long long g_wmsa_stamps[256][8];
+__device__ __forceinline__ long long stamp_now() {
+  long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define STAMP_TO(i) do { if constexpr (STAMP) { const long long now_ = stamp_now(); acc_st[i] += now_ - last_st; last_st = now_; } } while (0)
+
+template <typename T, int NWV, int NST, bool SAVE, bool STAMP = false>
 __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) {
   using L = WL<T>;
   constexpr int E = L::E, KPL = L::KPL, NT = NWV * 64;
@@ -127,61 +200,92 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
   constexpr int NPF = (NCHK + NT - 1) / NT;              // per thread: 7 (bf16, 256 threads) / 26 (f32, 128 threads)
   typedef typename K16<T>::type k16_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // smem: LN1 tiles [NWV][64][ROWB] | stages [NST][STAGE] | v patches [NWV][64][16]
+  // smem: LN1 tiles [NWV][64][ROWB] | stages [NST][STAGE] | v patches [NWV][64][16] | proj bias + LayerNorm vectors
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, t = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), t = lane & 15, g = lane >> 4;
   // LDS byte offsets as  per-lane base (one VGPR) + compile-time immediate.  LN1 tile: chunk c = 4 k + g of token row
   // r = 16 ms + t sits at chunk c ^ (r & 7) = 4 (k ^ b) + (g ^ (t & 3)), b = bit 2 of t: even k moves by +64 b bytes,
   // odd k by -64 b, so two bases serve every (ms, k).
-  constexpr unsigned SST0 = NWV * L::XNB, SVP0 = SST0 + NST * L::STAGE;
+  constexpr unsigned SST0 = NWV * L::XNB, SVP0 = SST0 + NST * L::STAGE, SLN0 = SVP0 + NWV * L::VPB;   // SLN0: bproj | g1 | b1 | g2 | b2 (f32)
   const unsigned xnb = (unsigned)(w * L::XNB);
   const unsigned gx3 = (unsigned)((g ^ (t & 3)) << 4);
   const unsigned xrow = xnb + (unsigned)(t * L::ROWB) + gx3, swb = (unsigned)(((t >> 2) & 1) * 64);
-  const unsigned xfE = xrow + swb, xfO = xrow - swb;
-#define XN_ADDR(ms, k) ((((k) & 1) ? xfO : xfE) + (unsigned)((ms) * 16 * L::ROWB + 64 * (k)))
+  const unsigned smem0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;      // LDS address of the arena
+  const unsigned xfE = smem0 + xrow + swb, xfO = smem0 + xrow - swb;
+#define XN_ADDR(ms, k) ((((k) & 1) ? xfO : xfE) - smem0 + (unsigned)((ms) * 16 * L::ROWB + 64 * (k)))
   // the same tile as the epilogue's f32 staging area [tokens][192] f32: chunk c4 of row r at c4 ^ (r & 3)
   const unsigned strow = xnb + (unsigned)(t * WC * 4) + gx3;
   const unsigned l16 = (unsigned)(lane * 16), lk16 = (unsigned)(lane * L::K16B);
   const unsigned vpw = SVP0 + (unsigned)(w * L::VPB) + (unsigned)((4 * g * WHD + t) * E);   // + (16 ms + r) * WHD * E
   const unsigned vpr = SVP0 + (unsigned)(w * L::VPB) + l16;
-  const bool save = a.xn1 != nullptr;
-  const unsigned char* tail = a.wpk + L::TAIL_OFF;       // f32: bproj | g1 | b1 | g2 | b2; read with 32-bit lane offsets
-  const unsigned goff = (unsigned)(g * KPL * 4);         // byte offset of this lane's first channel inside a 4-chunk group
+  constexpr bool save = SAVE;          // training build: the save-for-backward outputs (their registers and address math exist only here)
+  // proj bias and the two LayerNorms' weight / bias: global -> LDS once per workgroup; lanes read them at
+  // lnb + (channel offset of their chunk) with immediates
+  for (int i = tid; i < 5 * WC / 4; i += NT) ((float4*)(smem + SLN0))[i] = ((const float4*)(a.wpk + L::TAIL_OFF))[i];
+  const unsigned lnb = SLN0 + (unsigned)(g * KPL * 4);    // this lane's first channel inside a 4-chunk group
   const float scale2 = 0.25f * WMSA_LOG2E;               // hd^-1/2 x log2 e
-
-  // ---- stage copy.  Double-buffered (bf16): global -> registers (in flight while a head computes) -> LDS; the loads are
-  // unconditional so that the slots stay registers (the chunks past STAGE belong to the next head / the tail of the
-  // pack buffer and are simply not written to LDS).  Single-buffered (f32 parity path): a plain copy loop between two
-  // barriers.
-  static_assert(NST == 1 || NPF == 7, "seven prefetch slots");
-  static_assert(NST == 1 || (WHEADS - 1) * L::STAGE + NPF * NT * 16 <= L::PACK_BYTES, "prefetch overrun stays inside the pack buffer");
-  uint4 pf0, pf1, pf2, pf3, pf4, pf5, pf6;                // individual registers: hipcc leaves an array of them in scratch
-#define PF_ISSUE(HEAD)                                                                  \
+  // compiler-visible LDS accesses go through POINTER bases + constant byte offsets (inbounds pointer arithmetic folds into
+  // the DS offset field; `unsigned` sums may wrap, so hipcc materialised - and spilled - one address VGPR per access)
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* const sm3 = (lds_u8*)smem;
+  lds_u8* p_vpw = sm3 + vpw;
+  lds_u8* p_vpr = sm3 + vpr;
+  // ---- stage copy.  Double-buffered (bf16): LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write), 1 KB per wave
+  // instruction, issued right after the hand-over barrier for the NEXT head and waited for (vmcnt) just before the next
+  // barrier.  The DMA is inline asm: hipcc does not know a VMEM operation is writing LDS, so it neither waits vmcnt(0)
+  // in front of the LDS accesses it can see nor reorders them (memory clobber).  Single-buffered (f32 parity path): a
+  // plain copy loop between two barriers.
+  static_assert(NST == 1 || NPF == 7, "seven 4 KB slices per stage");
+#define PF_ISSUE(BUF, HEAD)                                                             \
   if constexpr (NST == 2) {                                                             \
-    const uint4* src_ = (const uint4*)(a.wpk + (unsigned)((HEAD) * L::STAGE)) + tid;    \
-    pf0 = src_[0]; pf1 = src_[NT]; pf2 = src_[2 * NT]; pf3 = src_[3 * NT];              \
-    pf4 = src_[4 * NT]; pf5 = src_[5 * NT]; pf6 = src_[6 * NT];                         \
+    const unsigned char* gsrc_ = a.wpk + (unsigned)((HEAD) * L::STAGE);                 \
+    const unsigned ldst_ = smem0 + SST0 + (unsigned)((BUF) * L::STAGE) + (unsigned)(w * 1024); \
+    const unsigned voff_ = (unsigned)(tid * 16);                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) {                                \
+      if (i_ < NPF - 1 || tid + (NPF - 1) * NT < NCHK)                                  \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"   \
+                     :: "v"(voff_), "s"(gsrc_ + i_ * NT * 16), "s"(ldst_ + (unsigned)(i_ * NT * 16)) : "memory", "m0"); \
+    }                                                                                   \
   }
-#define PF_STORE(BUF, HEAD)                                                             \
-  if constexpr (NST == 2) {                                                             \
-    uint4* dst_ = (uint4*)(smem + SST0 + (unsigned)((BUF) * L::STAGE)) + tid;           \
-    dst_[0] = pf0; dst_[NT] = pf1; dst_[2 * NT] = pf2; dst_[3 * NT] = pf3;              \
-    dst_[4 * NT] = pf4; dst_[5 * NT] = pf5;                                             \
-    if (tid + 6 * NT < NCHK) dst_[6 * NT] = pf6;                                        \
-  } else {                                                                              \
+#define PF_WAIT() do { if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define PF_COPY(HEAD)                                                                   \
+  if constexpr (NST == 1) {                                                             \
     const uint4* src_ = (const uint4*)(a.wpk + (unsigned)((HEAD) * L::STAGE));          \
     uint4* dst_ = (uint4*)(smem + SST0);                                                \
     for (int idx_ = tid; idx_ < NCHK; idx_ += NT) dst_[idx_] = src_[idx_];              \
   }
-  PF_ISSUE(0)
-  PF_STORE(0, 0)
+  PF_ISSUE(0, 0)
+  PF_COPY(0)
   int sidx = 0;
+  long long acc_st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_st = 0;
+  if constexpr (STAMP) last_st = stamp_now();
 
   // bias-table addressing of this lane (see the header): four consecutive entries r = 0..3 at one aligned address
   const int j0 = 7 - (t & 7) + 4 * (g & 1), jv = j0 & 3;
   const int bias_lane_off = L::BIAS_OFF + (((jv * 15 + (t >> 3) - (g >> 1) + 7) * 16) + (j0 - jv)) * E;   // strip difference 0
 
   const int nquads = (a.nwin + NWV - 1) / NWV;
+  // token rows of window-quad `q` for this lane (clamped for the tail): byte offsets of its four token strips
+  auto strip_offsets = [&](int q, unsigned* ro) {
+    int it_ = q * NWV + w;
+    if (it_ >= a.nwin) it_ = a.nwin - 1;
+    const int wx_ = it_ % a.nwx; it_ /= a.nwx;
+    const int wy_ = it_ % a.nwy; const int b_ = it_ / a.nwy;
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) ro[ms] = (unsigned)wtoken(a, b_, wy_, wx_, 16 * ms + t) * (unsigned)L::ROWB + (unsigned)(g * 16);
+  };
+  // x of the NEXT window is requested before the current window's output stores (loads and stores retire in issue
+  // order per wave: a load behind a store waits for the store's acknowledgement) and lands during the epilogue
+  uint4 xc[4][L::CHL];
+  if (NST == 2 && (int)blockIdx.x < nquads) {
+    unsigned ro[4];
+    strip_offsets(blockIdx.x, ro);
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+      for (int i = 0; i < L::CHL; ++i) xc[ms][i] = *(const uint4*)(a.x + (ro[ms] + 64u * i));
+  }
+  __syncthreads();                                       // LayerNorm vectors are in LDS
   for (int it = blockIdx.x; it < nquads; it += gridDim.x) {
     int item = it * NWV + w;
     const bool valid = item < a.nwin;
@@ -214,12 +318,28 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
     }
 
     // ================= prologue: LN1 of the window -> LDS tile (and xn1 / st1 when saving)
+    // Prologue and epilogue re-derive their per-lane addresses from a LAUNDERED lane id: values that stayed live across
+    // the head loop would be spilled there and reloaded here through scratch - a VMEM round trip queued behind stores.
     {
-      uint4 xc[4][L::CHL];
+      int lane_p = (int)(threadIdx.x & 63);
+      LAUNDER(lane_p);
+      const int tp = lane_p & 15, gp = lane_p >> 4;
+      unsigned prow[4], poff[4];
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms)
+      for (int ms = 0; ms < 4; ++ms) {
+        prow[ms] = (unsigned)wtoken(a, b, wy, wx, 16 * ms + tp);
+        poff[ms] = prow[ms] * (unsigned)L::ROWB + (unsigned)(gp * 16);
+      }
+      lds_u8* q_ln = sm3 + SLN0 + gp * KPL * 4;
+      const unsigned prow0 = (unsigned)(w * L::XNB + tp * L::ROWB + ((gp ^ (tp & 3)) << 4)), psw = (unsigned)(((tp >> 2) & 1) * 64);
+      lds_u8* q_xE = sm3 + prow0 + psw;
+      lds_u8* q_xO = sm3 + prow0 - psw;
+      if constexpr (NST == 1) {   // parity build: no cross-window prefetch
 #pragma unroll
-        for (int i = 0; i < L::CHL; ++i) xc[ms][i] = *(const uint4*)(a.x + (roff[ms] + 64u * i));
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+          for (int i = 0; i < L::CHL; ++i) xc[ms][i] = *(const uint4*)(a.x + (poff[ms] + 64u * i));
+      }
       float mean[4], rstd[4];
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms) {
@@ -231,7 +351,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
 #pragma unroll
           for (int j = 0; j < KPL; ++j) s += f[j];
         }
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        s = rows_sum(s);
         const float mu = s * (1.0f / WC);
         float q = 0.f;
 #pragma unroll
@@ -241,20 +361,19 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
 #pragma unroll
           for (int j = 0; j < KPL; ++j) { const float d = f[j] - mu; q = fmaf(d, d, q); }
         }
-        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+        q = rows_sum(q);
         mean[ms] = mu;
         rstd[ms] = rsqrtf(q * (1.0f / WC) + 1e-5f);
-        if (save && valid && g == 0) *(float2*)((unsigned char*)a.st1 + rows[ms] * 8u) = make_float2(mu, rstd[ms]);
+        if (save && valid && gp == 0) *(float2*)((unsigned char*)a.st1 + prow[ms] * 8u) = make_float2(mu, rstd[ms]);
       }
       wave_sync();                                       // the previous window's epilogue is done with the tile
 #pragma unroll
       for (int i = 0; i < L::CHL; ++i) {
-        const int c = 4 * i + g;
         float ga[KPL], be[KPL];
 #pragma unroll
         for (int j = 0; j < KPL; j += 4) {
-          *(float4*)(ga + j) = *(const float4*)(tail + (goff + (unsigned)((WC + 4 * i * KPL + j) * 4)));
-          *(float4*)(be + j) = *(const float4*)(tail + (goff + (unsigned)((2 * WC + 4 * i * KPL + j) * 4)));
+          *(f32x4*)(ga + j) = *(const __attribute__((address_space(3))) f32x4*)(q_ln + (WC + 4 * i * KPL + j) * 4);
+          *(f32x4*)(be + j) = *(const __attribute__((address_space(3))) f32x4*)(q_ln + (2 * WC + 4 * i * KPL + j) * 4);
         }
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
@@ -263,13 +382,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
 #pragma unroll
           for (int j = 0; j < KPL; ++j) f[j] = fmaf((f[j] - mean[ms]) * rstd[ms], ga[j], be[j]);
           const uint4 y = pack<T>(f);
-          *(uint4*)(smem + XN_ADDR(ms, i)) = y;
-          if (save && valid) *(uint4*)(a.xn1 + (roff[ms] + 64u * i)) = y;
+          *(__attribute__((address_space(3))) u32x4_*)(((i & 1) ? q_xO : q_xE) + (ms * 16 * L::ROWB + 64 * i)) = u32x4_{y.x, y.y, y.z, y.w};
+          if (save && valid) *(uint4*)(a.xn1 + (poff[ms] + 64u * i)) = y;
         }
       }
       wave_sync();
     }
 
+    STAMP_TO(6);
     // ================= the 12 heads
     f32x4 outT[WHEADS][4];                               // out^T: [n strip][token strip], row = channel 16 n + 4 g + r, column = token t
 #pragma unroll
@@ -279,39 +399,86 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
 
     for (int h = 0; h < WHEADS; ++h) {
       const int buf = NST == 2 ? (sidx & 1) : 0;
+      STAMP_TO(5);
+      PF_WAIT();                                         // this wave's slices of stage `buf` have landed
       __syncthreads();                                   // stage `buf` is complete; everyone has left the other buffer
+      STAMP_TO(0);
       const unsigned sbo = SST0 + (unsigned)(buf * L::STAGE);      // this head's stage
-      const unsigned wb16 = sbo + l16, wbk = sbo + L::WP_OFF + lk16, bb = sbo + (unsigned)bias_lane_off;
+      const unsigned wb16 = smem0 + sbo + l16, wbk = smem0 + sbo + lk16;
+      const unsigned bb3 = smem0 + sbo + (unsigned)bias_lane_off - (unsigned)(3 * 2 * 16 * E);       // strip difference -3
+      const unsigned sbg = smem0 + sbo + (unsigned)(16 * g), sbt = smem0 + sbo + (unsigned)(4 * t);
       const int hnext = h + 1 == WHEADS ? 0 : h + 1;
-      PF_ISSUE(hnext)
+      PF_ISSUE(buf ^ 1, hnext)
 
       auto body = [&](auto MSK_) {
         constexpr bool MSK = decltype(MSK_)::value;
-        // ---- q^T, k^T (channel rows, token columns) and v (token rows, channel columns) of this head
-        f32x4 qT[4], kT[4], vv[4];
-        {
-          const unsigned bqo = sbo + L::BQKV_OFF;
-          const f32x4 bqv = *(const f32x4*)(smem + (bqo + (unsigned)(16 * g))), bkv = *(const f32x4*)(smem + (bqo + (unsigned)(64 + 16 * g)));
-          const float bvs = *(const float*)(smem + (bqo + (unsigned)(128 + 4 * t)));
-#pragma unroll
-          for (int ms = 0; ms < 4; ++ms) { qT[ms] = bqv; kT[ms] = bkv; vv[ms] = f32x4{bvs, bvs, bvs, bvs}; }
-        }
-#pragma unroll
-        for (int kk = 0; kk < L::KSTEPS; ++kk) {
-          const uint4 wq = *(const uint4*)(smem + (wb16 + (unsigned)(L::WQ_OFF + kk * 1024)));
-          const uint4 wk = *(const uint4*)(smem + (wb16 + (unsigned)(L::WK_OFF + kk * 1024)));
-          const uint4 wv = *(const uint4*)(smem + (wb16 + (unsigned)(L::WV_OFF + kk * 1024)));
-#pragma unroll
-          for (int ms = 0; ms < 4; ++ms) {
-            const uint4 xf = *(const uint4*)(smem + XN_ADDR(ms, kk));
-            mma16<T>(qT[ms], wq, xf);
-            mma16<T>(kT[ms], wk, xf);
-            mma16<T>(vv[ms], xf, wv);
-          }
-        }
+        // ---- q^T, k^T (channel rows, token columns) and v (token rows, channel columns) of this head.
+        // LDS issue order: q/k/v bias (3) + table entries (7), fragments of k-step 0 (7), then per k-step the fragments of
+        // the next one (7) - or, at the last, this head's Wproj slice (12) - BEFORE the 12 MFMAs of the current step.
+        typedef typename KR<T>::type kreg_t;
+        u32x4_ bqr = lds_rd128a<L::BQKV_OFF>(sbg), bkr = lds_rd128a<L::BQKV_OFF + 64>(sbg);
+        unsigned bvr = lds_rd32a<L::BQKV_OFF + 128>(sbt);
+        kreg_t biar[7];
+        static_for<0, 7>([&](auto d_) { constexpr int d = decltype(d_)::value; biar[d] = KR<T>::template rd<d * 2 * 16 * E>(bb3); });
+        // two passes over the token strips (pairs 0-1, 2-3): 24 instead of 48 transient accumulator registers beside the 192
+        // of out^T (the Wq/Wk/Wv fragments are read twice: +18 LDS reads per head)
+        u32x4_ wf[2][3], xf[2][2];
+        kreg_t wpr[WHEADS];
+        constexpr int NSTEP = 2 * L::KSTEPS;             // step = (strip pair, k-step)
+        auto issue_k = [&](auto st_) {
+          constexpr int st = decltype(st_)::value, bsel = st & 1, hp = st / L::KSTEPS, kk = st % L::KSTEPS;
+          wf[bsel][0] = lds_rd128a<L::WQ_OFF + kk * 1024>(wb16);
+          wf[bsel][1] = lds_rd128a<L::WK_OFF + kk * 1024>(wb16);
+          wf[bsel][2] = lds_rd128a<L::WV_OFF + kk * 1024>(wb16);
+          xf[bsel][0] = lds_rd128a<(2 * hp) * 16 * L::ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
+          xf[bsel][1] = lds_rd128a<(2 * hp + 1) * 16 * L::ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
+        };
+        issue_k(std::integral_constant<int, 0>{});
         k16_t pq[4], pkk[4], pv[4];
+        f32x4 qT[2], kT[2], vv[2];
+        f32x4 bqv, bkv;
+        float bvs = 0.f;
+        static_for<0, NSTEP>([&](auto st_) {
+          constexpr int st = decltype(st_)::value, bsel = st & 1, hp = st / L::KSTEPS, kk = st % L::KSTEPS;
+          if constexpr (st + 1 < NSTEP) {
+            issue_k(std::integral_constant<int, st + 1>{});
+            LDS_WAIT(5);
+          } else {
+            static_for<0, WHEADS>([&](auto n_) { constexpr int n = decltype(n_)::value; wpr[n] = KR<T>::template rd<L::WP_OFF + n * 64 * L::K16B>(wbk); });
+            LDS_WAIT(12);
+          }
+          LDS_DEP(wf[bsel][0]); LDS_DEP(wf[bsel][1]); LDS_DEP(wf[bsel][2]);
+          LDS_DEP(xf[bsel][0]); LDS_DEP(xf[bsel][1]);
+          if constexpr (st == 0) {
+            LDS_DEP(bqr); LDS_DEP(bkr); LDS_DEP(bvr);
+            bqv = KR<float>::f4(bqr); bkv = KR<float>::f4(bkr);
+            bvs = __uint_as_float(bvr);
+          }
+          if constexpr (kk == 0) {
 #pragma unroll
-        for (int ms = 0; ms < 4; ++ms) { pq[ms] = pk16<T>(qT[ms]); pkk[ms] = pk16<T>(kT[ms]); pv[ms] = pk16<T>(vv[ms]); }
+            for (int ml = 0; ml < 2; ++ml) { qT[ml] = bqv; kT[ml] = bkv; vv[ml] = f32x4{bvs, bvs, bvs, bvs}; }
+          }
+          const uint4 wq = u4(wf[bsel][0]), wk = u4(wf[bsel][1]), wv = u4(wf[bsel][2]);
+#pragma unroll
+          for (int ml = 0; ml < 2; ++ml) {
+            const uint4 x4 = u4(xf[bsel][ml]);
+            mma16<T>(qT[ml], wq, x4);
+            mma16<T>(kT[ml], wk, x4);
+            mma16<T>(vv[ml], x4, wv);
+          }
+          if constexpr (kk == L::KSTEPS - 1) {
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml) {
+              pq[2 * hp + ml] = pk16<T>(qT[ml]); pkk[2 * hp + ml] = pk16<T>(kT[ml]); pv[2 * hp + ml] = pk16<T>(vv[ml]);
+              if constexpr (SAVE) {     // v -> [token][16] patch (the accumulator holds four tokens of ONE channel per lane)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  *(__attribute__((address_space(3))) T*)(p_vpw + (16 * (2 * hp + ml) + r) * WHD * E) = from_f<T>(vv[ml][r]);
+              }
+            }
+          }
+        });
+        STAMP_TO(1);
         if (save && valid) {
           unsigned char* qb = a.qkvw + (size_t)(whoff + h) * (3 * 64 * WHD * E);     // uniform
           const unsigned lo = (unsigned)(t * (WHD * E) + g * L::K16B);
@@ -320,30 +487,17 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
             *(k16_t*)(qb + (lo + (unsigned)(16 * ms * WHD * E))) = pq[ms];
             *(k16_t*)(qb + (lo + (unsigned)(64 * WHD * E + 16 * ms * WHD * E))) = pkk[ms];
           }
-          // v: [token][16] through the patch (the accumulator holds four tokens of ONE channel per lane)
-#pragma unroll
-          for (int ms = 0; ms < 4; ++ms)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) *(T*)(smem + (vpw + (unsigned)((16 * ms + r) * WHD * E))) = from_f<T>(vv[ms][r]);
           wave_sync();
 #pragma unroll
           for (int i = 0; i < L::VPB / 1024; ++i)
-            *(uint4*)(qb + (unsigned)(2 * 64 * WHD * E + (i * 64 + lane) * 16)) = *(const uint4*)(smem + (vpr + (unsigned)(i * 1024)));
+            *(uint4*)(qb + (unsigned)(2 * 64 * WHD * E + (i * 64 + lane) * 16)) = u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)(p_vpr + i * 1024));
           wave_sync();
         }
+        STAMP_TO(2);
         // ---- S^T = K Q^T: row = key 16 ks + 4 g + r, column = query 16 ms + t; softmax per query
         f32x4 bia[7];
 #pragma unroll
-        for (int d = 0; d < 7; ++d) {
-          const unsigned char* p = smem + ((bb - (unsigned)(3 * 2 * 16 * E)) + (unsigned)(d * 2 * 16 * E));   // strip difference d - 3
-          if constexpr (std::is_same<T, bf16>::value) {
-            const uint2 u = *(const uint2*)p;
-            bia[d] = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                           __uint_as_float(u.y & 0xffff0000u)};
-          } else {
-            bia[d] = *(const f32x4*)p;
-          }
-        }
+        for (int d = 0; d < 7; ++d) { LDS_DEP(biar[d]); bia[d] = KR<T>::f4(biar[d]); }     // older than every fragment read: landed
         k16_t pp[4][4];                                  // P^T strips, packed: [ks][ms]
         float inv[4];
 #pragma unroll
@@ -361,8 +515,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
               s[ks][r] = v;
               mx = fmaxf(mx, v);
             }
-          mx = fmaxf(mx, __shfl_xor(mx, 16));
-          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          mx = rows_max(mx);
           float sum = 0.f;
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
@@ -370,12 +523,12 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
             for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(s[ks][r] - mx); s[ks][r] = p; sum += p; }
             pp[ks][ms] = pk16<T>(s[ks]);
           }
-          sum += __shfl_xor(sum, 16);
-          sum += __shfl_xor(sum, 32);
+          sum = rows_sum(sum);
           inv[ms] = __builtin_amdgcn_rcpf(sum);
           if (save && valid && g == 0)
             (a.lsew + (size_t)(whoff + h) * 64)[16 * ms + t] = mx * (1.0f / WMSA_LOG2E) + __logf(sum);
         }
+        STAMP_TO(3);
         // ---- O^T = V^T P^T: row = channel 4 g + r, column = query; then out^T += Wproj[:, h] O^T
         k16_t po[4];
 #pragma unroll
@@ -394,87 +547,119 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
           po[ms] = pk16<T>(o);
           if (save && valid) *(k16_t*)(a.ao + (size_t)(WHD * h * E) + (roff[ms] - (unsigned)(g * (16 - L::K16B)))) = po[ms];
         }
+        LDS_WAIT(0);
 #pragma unroll
         for (int n = 0; n < WHEADS; ++n) {
-          const k16_t wp = *(const k16_t*)(smem + (wbk + (unsigned)(n * 64 * L::K16B)));
+          LDS_DEP(wpr[n]);
+          const k16_t wp = KR<T>::op(wpr[n]);
 #pragma unroll
           for (int ms = 0; ms < 4; ++ms) mmak16(outT[n][ms], wp, po[ms]);
         }
       };
       if (msk) body(std::true_type{}); else body(std::false_type{});
+      STAMP_TO(4);
 
       if (NST == 1) __syncthreads();                     // single buffer: everyone is done reading before it is refilled
-      PF_STORE(NST == 2 ? (buf ^ 1) : 0, hnext)
+      PF_COPY(hnext)
       ++sidx;
     }
 
-    // ================= epilogue: x_mid = x + out + bproj, xn2 = LN2(x_mid)
-    constexpr int MSP = 4 / L::PASSES;                   // token strips per pass through the (f32) tile
+    STAMP_TO(5);
+    // ================= epilogue: x_mid = x + (out + bproj), xn2 = LN2(x_mid)
+    // out^T + bias is staged through the wave's (dead) LN1 tile in the run dtype - for bf16 that is the rounding a separate
+    // projection launch (or torch autocast: F.linear returns bf16, then shortcut + x) applies to its output - which drains all
+    // 192 accumulator registers at once.  Load / store order: VMEM operations of a wave retire in issue order, so every load
+    // of the epilogue - the residual x, and the x of the NEXT window - is issued before the first store; a load queued
+    // behind a store would wait for the store's acknowledgement from memory.  Per-lane addresses are re-derived from a
+    // laundered lane id (see the prologue).
+    int lane_e = (int)(threadIdx.x & 63);
+    LAUNDER(lane_e);
+    const int te = lane_e & 15, ge = lane_e >> 4;
+    unsigned erow[4], eoff[4];
 #pragma unroll
-    for (int ps = 0; ps < L::PASSES; ++ps) {
-      wave_sync();
+    for (int ms = 0; ms < 4; ++ms) {
+      erow[ms] = (unsigned)wtoken(a, b, wy, wx, 16 * ms + te);
+      eoff[ms] = erow[ms] * (unsigned)L::ROWB + (unsigned)(ge * 16);
+    }
+    uint4 xr[4][L::CHL];
 #pragma unroll
-      for (int ml = 0; ml < MSP; ++ml) {
-        const int ms = ps * MSP + ml;
+    for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
-        for (int n = 0; n < WHEADS; ++n) {
-          const f32x4 bp = *(const f32x4*)(tail + ((unsigned)(g * 16) + (unsigned)(64 * n)));
-          *(f32x4*)(smem + (strow + (unsigned)(ml * 16 * WC * 4 + 64 * n))) = outT[n][ms] + bp;     // chunk (4 n + g) ^ (t & 3)
-        }
+      for (int i = 0; i < L::CHL; ++i) xr[ms][i] = *(const uint4*)(a.x + (eoff[ms] + 64u * i));
+    lds_u8* e_ln = sm3 + SLN0 + ge * KPL * 4;
+    lds_u8* e_bp = sm3 + SLN0 + ge * 16;
+    lds_u8* e_row = sm3 + w * L::XNB + te * L::ROWB;     // token 16 ms + te of the tile: + ms * 16 * ROWB
+    wave_sync();                                         // the heads are done reading the tile
+#pragma unroll
+    for (int n = 0; n < WHEADS; ++n) {
+      const f32x4 bp = *(const __attribute__((address_space(3))) f32x4*)(e_bp + 64 * n);
+      // channels 16 n + 4 ge .. + 3: byte (16 n + 4 ge) E of the row = chunk cw, sub-offset sb; stored at chunk cw ^ (te & 7)
+      const int cb = (16 * n + 4 * ge) * E, cw = cb >> 4, sb = cb & 15;
+      lds_u8* dst = e_row + (((cw ^ (te & 7)) << 4) + sb);
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+        *(__attribute__((address_space(3))) typename KR<T>::type*)(dst + ms * 16 * L::ROWB) = KR<T>::reg(pk16<T>(outT[n][ms] + bp));
+    }
+    if constexpr (NST == 2) {     // next window's x (unconditional, clamped: the old xc dies in the prologue, not across the heads)
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned ro[4];
+      strip_offsets(it + (int)gridDim.x < nquads ? it + (int)gridDim.x : it, ro);
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+        for (int i = 0; i < L::CHL; ++i) xc[ms][i] = *(const uint4*)(a.x + (ro[ms] + 64u * i));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_sync();
+    const unsigned esw = (unsigned)(((te >> 2) & 1) * 64);
+    lds_u8* e_rE = e_row + ((ge ^ (te & 3)) << 4) + esw;   // chunk 4 i + ge of the row: even i at +64 b, odd i at -64 b (see XN_ADDR)
+    lds_u8* e_rO = e_row + ((ge ^ (te & 3)) << 4) - esw;
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      float v[L::CHL][KPL];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < L::CHL; ++i) {
+        float f[KPL], o[KPL];
+        unpack<T>(xr[ms][i], f);
+        unpack<T>(u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)(((i & 1) ? e_rO : e_rE) + (ms * 16 * L::ROWB + 64 * i))), o);
+        // x_mid is stored in T: LN2 normalises the ROUNDED value, exactly as a separate LayerNorm launch reading x_mid would
+        // (and as the LayerNorm backward, which re-reads x_mid, assumes)
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) { v[i][j] = to_f(from_f<T>(f[j] + o[j])); s += v[i][j]; }
       }
-      wave_sync();
+      s = rows_sum(s);
+      const float mu = s * (1.0f / WC);
+      float q = 0.f;
 #pragma unroll
-      for (int ml = 0; ml < MSP; ++ml) {
-        const int ms = ps * MSP + ml;
-        float v[L::CHL][KPL];
-        float s = 0.f;
+      for (int i = 0; i < L::CHL; ++i)
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) { const float d = v[i][j] - mu; q = fmaf(d, d, q); }
+      q = rows_sum(q);
+      const float rs = rsqrtf(q * (1.0f / WC) + 1e-5f);
+      if (valid) {
+        if (save && ge == 0) *(float2*)((unsigned char*)a.st2 + erow[ms] * 8u) = make_float2(mu, rs);
 #pragma unroll
         for (int i = 0; i < L::CHL; ++i) {
-          float f[KPL];
-          unpack<T>(*(const uint4*)(a.x + (roff[ms] + 64u * i)), f);
+          const uint4 xmv = pack<T>(v[i]);
+          *(uint4*)(a.xm + (eoff[ms] + 64u * i)) = xmv;
+          float f[KPL], ga[KPL], be[KPL];
 #pragma unroll
           for (int j = 0; j < KPL; j += 4) {
-            // f32 chunk c4 = (c KPL + j) / 4 of channels c KPL + j .. + 3, stored at c4 ^ (t & 3)
-            const unsigned lowc = (unsigned)((((g * KPL + j) >> 2) & 3) ^ (t & 3)), hic = (unsigned)(((g * KPL + j) >> 2) >> 2);
-            const f32x4 o = *(const f32x4*)(smem + (xnb + (unsigned)(t * WC * 4) + ((hic * 4 + lowc) << 4) +
-                                                    (unsigned)(ml * 16 * WC * 4 + i * KPL * 16)));
-            // x_mid is stored in T: LN2 normalises the ROUNDED value, exactly as a separate LayerNorm launch reading x_mid
-            // would (and as the LayerNorm backward, which re-reads x_mid, assumes)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) v[i][j + q4] = to_f(from_f<T>(f[j + q4] + o[q4]));
+            *(f32x4*)(ga + j) = *(const __attribute__((address_space(3))) f32x4*)(e_ln + (3 * WC + 4 * i * KPL + j) * 4);
+            *(f32x4*)(be + j) = *(const __attribute__((address_space(3))) f32x4*)(e_ln + (4 * WC + 4 * i * KPL + j) * 4);
           }
 #pragma unroll
-          for (int j = 0; j < KPL; ++j) s += v[i][j];
-        }
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-        const float mu = s * (1.0f / WC);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < L::CHL; ++i)
-#pragma unroll
-          for (int j = 0; j < KPL; ++j) { const float d = v[i][j] - mu; q = fmaf(d, d, q); }
-        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-        const float rs = rsqrtf(q * (1.0f / WC) + 1e-5f);
-        if (valid) {
-          if (save && g == 0) *(float2*)((unsigned char*)a.st2 + rows[ms] * 8u) = make_float2(mu, rs);
-#pragma unroll
-          for (int i = 0; i < L::CHL; ++i) {
-            const int c = 4 * i + g;
-            const uint4 xmv = pack<T>(v[i]);
-            *(uint4*)(a.xm + (roff[ms] + 64u * i)) = xmv;
-            float f[KPL], ga[KPL], be[KPL];
-#pragma unroll
-            for (int j = 0; j < KPL; j += 4) {
-              *(float4*)(ga + j) = *(const float4*)(tail + (goff + (unsigned)((3 * WC + 4 * i * KPL + j) * 4)));
-              *(float4*)(be + j) = *(const float4*)(tail + (goff + (unsigned)((4 * WC + 4 * i * KPL + j) * 4)));
-            }
-#pragma unroll
-            for (int j = 0; j < KPL; ++j) f[j] = fmaf((v[i][j] - mu) * rs, ga[j], be[j]);
-            *(uint4*)(a.xn2 + (roff[ms] + 64u * i)) = pack<T>(f);
-          }
+          for (int j = 0; j < KPL; ++j) f[j] = fmaf((v[i][j] - mu) * rs, ga[j], be[j]);
+          *(uint4*)(a.xn2 + (eoff[ms] + 64u * i)) = pack<T>(f);
         }
       }
     }
+    STAMP_TO(7);
+  }
+  if constexpr (STAMP) {
+    if (tid == 0 && blockIdx.x < 256)
+      for (int i = 0; i < 8; ++i) g_wmsa_stamps[blockIdx.x][i] = acc_st[i];
   }
 }
 
@@ -524,13 +709,15 @@ __global__ __launch_bounds__(256) void wmsa_pack_kernel(const float* __restrict_
   for (int i = tid; i < 64; i += 256) bq[i] = i < 48 ? qkv_b[(i / 16) * WC + WHD * h + (i % 16)] : 0.f;
 }
 
-template <typename T, int NWV, int NST>
+bool g_wmsa_stamp_enable = false;
+
+template <typename T, int NWV, int NST, bool SAVE, bool STAMP = false>
 int launch_block(const WArgs& a, hipStream_t st) {
   using L = WL<T>;
-  constexpr int LDS = NWV * L::XNB + NST * L::STAGE + NWV * L::VPB;
+  constexpr int LDS = NWV * L::XNB + NST * L::STAGE + NWV * L::VPB + 5 * WC * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = wmsa_block_kernel<T, NWV, NST>;
+  auto kern = wmsa_block_kernel<T, NWV, NST, SAVE, STAMP>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       (void)hipGetLastError();
@@ -585,7 +772,19 @@ extern "C" int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, voi
   a.xn1 = (unsigned char*)xn1; a.qkvw = (unsigned char*)qkvw; a.lsew = lsew; a.ao = (unsigned char*)ao;
   a.B = B; a.H = H; a.W = W; a.shift = shift; a.nwy = H / WWS; a.nwx = W / WWS; a.nwin = B * a.nwy * a.nwx;
   hipStream_t st = (hipStream_t)st_;
-  if (dtype == SODT_BF16) return launch_block<bf16, 4, 2>(a, st);
-  if (dtype == SODT_F32) return launch_block<float, 2, 1>(a, st);
+  if (dtype == SODT_BF16) {
+    if (g_wmsa_stamp_enable) return save ? launch_block<bf16, 4, 2, true, true>(a, st) : launch_block<bf16, 4, 2, false, true>(a, st);
+    return save ? launch_block<bf16, 4, 2, true>(a, st) : launch_block<bf16, 4, 2, false>(a, st);
+  }
+  if (dtype == SODT_F32) return save ? launch_block<float, 2, 1, true>(a, st) : launch_block<float, 2, 1, false>(a, st);
   return SODT_EINVAL;
+}
+
+/* diagnostic hook (tools/mb_wmsa.py --stamps): enable != 0 makes the following bf16 launches run the instrumented
+ * build; out (host, 256 x 8 long long, nullable) receives the per-phase shader-cycle sums of wave 0 of each
+ * workgroup of the last such launch: [barrier wait, QKV, pack/save, S+softmax, PV+proj, stage store, prologue, epilogue] */
+extern "C" int sodt_debug_wmsa_stamps(long long* out, int enable) {
+  g_wmsa_stamp_enable = enable != 0;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wmsa_stamps), sizeof(long long) * 256 * 8) != hipSuccess) return SODT_EINVAL;
+  return SODT_OK;
 }

@@ -50,3 +50,20 @@ def unf():
     ops.layernorm_fwd(xm, n2w, n2b, xn2, st2, M, C)
 u = timeit(unf) - tz
 print(f"unfused (LN1, QKV GEMM, attention, proj GEMM, LN2): {u:.3f} ms", flush=True)
+
+if "--stamps" in sys.argv:
+    import ctypes
+    lib = L.load()
+    names = ["barrier wait", "QKV", "pack/save", "S+softmax", "PV+proj", "stage store", "prologue", "epilogue"]
+    for label, fn in (("inference", lambda: ops.wmsa_block_fwd(x, wpk, xm, xn2, None, None, None, None, None, None, B, H, H, C, HEADS, WS, 0)),
+                      ("training", lambda: ops.wmsa_block_fwd(x, wpk, xm, xn2, st1, st2, xn1, qkvw, lsew, ao, B, H, H, C, HEADS, WS, 0))):
+        lib.sodt_debug_wmsa_stamps(None, 1)
+        fn(); torch.cuda.synchronize(); big.zero_(); fn(); torch.cuda.synchronize()
+        buf = (ctypes.c_longlong * (256 * 8))()
+        lib.sodt_debug_wmsa_stamps(buf, 0)
+        t = torch.tensor(list(buf), dtype=torch.float64).view(256, 8)
+        tot = t.sum(1).mean()
+        print(f"stamps ({label}; mean over 256 workgroups, wave 0; cycles per launch {tot:.0f}):")
+        for i, n in enumerate(names):
+            per = t[:, i].mean() / (M / 64 / 1024 * (12 if i < 6 else 1))
+            print(f"   {n:14s} {t[:, i].mean():12.0f} cycles = {100 * t[:, i].mean() / tot:5.1f} %   ({per:8.0f} per {'head' if i < 6 else 'window'})")
