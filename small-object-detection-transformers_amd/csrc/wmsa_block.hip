@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
 
   const int nquads = (a.nwin + NWV - 1) / NWV;
   // token rows of window-quad `q` for this lane (clamped for the tail): byte offsets of its four token strips
-  auto strip_offsets = [&](int q, unsigned* ro) {
+  auto strip_offsets = [&](int q, unsigned* ro, int t, int g) {      // t, g: the caller's (laundered) lane coordinates
     int it_ = q * NWV + w;
     if (it_ >= a.nwin) it_ = a.nwin - 1;
     const int wx_ = it_ % a.nwx; it_ /= a.nwx;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
   uint4 xc[4][L::CHL];
   if (NST == 2 && (int)blockIdx.x < nquads) {
     unsigned ro[4];
-    strip_offsets(blockIdx.x, ro);
+    strip_offsets(blockIdx.x, ro, t, g);
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
@@ -294,14 +294,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
     const int wx = tq % a.nwx; tq /= a.nwx;
     const int wy = tq % a.nwy; const int b = tq / a.nwy;
     const bool msk = a.shift > 0 && (wy == a.nwy - 1 || wx == a.nwx - 1);
-    // every global access of the window is  uniform base + 32-bit byte offset (+ immediate): one VGPR per token strip
-    // (row * ROWB < 2^31 is checked on the host), not a 64-bit pointer per access held across the head loop
-    unsigned rows[4], roff[4];
-#pragma unroll
-    for (int ms = 0; ms < 4; ++ms) {
-      rows[ms] = (unsigned)wtoken(a, b, wy, wx, 16 * ms + t);
-      roff[ms] = rows[ms] * (unsigned)L::ROWB + (unsigned)(g * 16);
-    }
     const unsigned whoff = (unsigned)item * WHEADS;       // (window, head 0) index of the window-major tensors
     // bit (4 ks + r) of diffm[ms]: query (ms, t) and key (ks, 4 g + r) lie in different mask regions
     unsigned diffm[4] = {0u, 0u, 0u, 0u};
@@ -444,8 +436,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
             issue_k(std::integral_constant<int, st + 1>{});
             LDS_WAIT(5);
           } else {
-            static_for<0, WHEADS>([&](auto n_) { constexpr int n = decltype(n_)::value; wpr[n] = KR<T>::template rd<L::WP_OFF + n * 64 * L::K16B>(wbk); });
-            LDS_WAIT(12);
+            static_for<0, WHEADS / 2>([&](auto n_) { constexpr int n = decltype(n_)::value; wpr[n] = KR<T>::template rd<L::WP_OFF + n * 64 * L::K16B>(wbk); });
+            LDS_WAIT(6);
           }
           LDS_DEP(wf[bsel][0]); LDS_DEP(wf[bsel][1]); LDS_DEP(wf[bsel][2]);
           LDS_DEP(xf[bsel][0]); LDS_DEP(xf[bsel][1]);
@@ -481,7 +473,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
         STAMP_TO(1);
         if (save && valid) {
           unsigned char* qb = a.qkvw + (size_t)(whoff + h) * (3 * 64 * WHD * E);     // uniform
-          const unsigned lo = (unsigned)(t * (WHD * E) + g * L::K16B);
+          int lane_s = (int)(threadIdx.x & 63);        // re-derived per head: a hoisted 64-bit address per store would live across the loop
+          LAUNDER(lane_s);
+          const unsigned lo = (unsigned)((lane_s & 15) * (WHD * E) + (lane_s >> 4) * L::K16B);
 #pragma unroll
           for (int ms = 0; ms < 4; ++ms) {
             *(k16_t*)(qb + (lo + (unsigned)(16 * ms * WHD * E))) = pq[ms];
@@ -545,11 +539,22 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
           }
           o *= inv[ms];
           po[ms] = pk16<T>(o);
-          if (save && valid) *(k16_t*)(a.ao + (size_t)(WHD * h * E) + (roff[ms] - (unsigned)(g * (16 - L::K16B)))) = po[ms];
+          if (save && valid) {
+            // token offset re-derived per head from a laundered lane id: four hoisted 64-bit store addresses (or their
+            // spilled 32-bit sources) would otherwise live across the whole head loop
+            int lane_o = (int)(threadIdx.x & 63);
+            LAUNDER(lane_o);
+            const unsigned ao_off = (unsigned)wtoken(a, b, wy, wx, 16 * ms + (lane_o & 15)) * (unsigned)L::ROWB + (unsigned)((lane_o >> 4) * L::K16B);
+            *(k16_t*)(a.ao + (size_t)(WHD * h * E) + ao_off) = po[ms];
+          }
         }
-        LDS_WAIT(0);
+        // Wproj slice: n-strips 0-5 were requested under the last QKV step; 6-11 are requested now and land under the first
+        // 24 MFMAs (fewer fragment registers alive across the softmax)
+        static_for<WHEADS / 2, WHEADS>([&](auto n_) { constexpr int n = decltype(n_)::value; wpr[n] = KR<T>::template rd<L::WP_OFF + n * 64 * L::K16B>(wbk); });
+        LDS_WAIT(6);
 #pragma unroll
         for (int n = 0; n < WHEADS; ++n) {
+          if (n == WHEADS / 2) LDS_WAIT(0);
           LDS_DEP(wpr[n]);
           const k16_t wp = KR<T>::op(wpr[n]);
 #pragma unroll
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
     if constexpr (NST == 2) {     // next window's x (unconditional, clamped: the old xc dies in the prologue, not across the heads)
       __builtin_amdgcn_sched_barrier(0);
       unsigned ro[4];
-      strip_offsets(it + (int)gridDim.x < nquads ? it + (int)gridDim.x : it, ro);
+      strip_offsets(it + (int)gridDim.x < nquads ? it + (int)gridDim.x : it, ro, te, ge);
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms)
 #pragma unroll

@@ -132,6 +132,7 @@ class Engine:
         # anchor that makes the autograd node require grad even if the caller froze everything else
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
         self.ddp = None     # set by ddp.attach()
+        self.use_fused_wmsa = True     # tests / tools may switch the fused block kernel off to compare with the four launches it replaces
         # 64 MiB of f32 for the per-slice partial tiles of the bf16 weight-gradient GEMMs (largest need: 12.5 M floats)
         self._tn_scratch = torch.empty(16 << 20, dtype=torch.float32, device=self.dev)
         ops.set_tn_scratch(self._tn_scratch)
@@ -261,13 +262,23 @@ class Engine:
             add(descs_f, self.params[E + f"chan_block.norm{ci + 1}.weight"], fe["g"][ci * 48:], (48, 1, 1), (0, 1, 2), 1)
             add(descs_f, self.params[E + f"chan_block.norm{ci + 1}.bias"], fe["be"][ci * 48:], (48, 1, 1), (0, 1, 2), 1)
 
+        # fused W-MSA block kernel (csrc/wmsa_block.hip): one stage-ordered parameter pack per eligible block
+        wmsa: Dict[str, torch.Tensor] = {}
+        code = L.BF16 if dt == torch.bfloat16 else L.F32
+        enc = self.model.image_encoder
+        for sname in ("stage1", "stage2", "stage3"):
+            for i, blk in enumerate(getattr(enc, sname)):
+                nb = ops.wmsa_pack_bytes(blk.dim, HEADS, blk.window_size, code) if self.use_fused_wmsa else 0
+                if nb > 0:
+                    wmsa[E + f"{sname}.{i}."] = torch.zeros(nb // (2 if dt == torch.bfloat16 else 4), device=dev, dtype=dt)
+
         def table(descs):
             arr = (L.PrepDesc * len(descs))(*descs)
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             mx = max(d.d0 * d.d1 * d.d2 for d in descs)
             return host.to(dev), len(descs), mx
         P = dict(w=w, wT=wT, wcat=wcat, bias_t=bias_t, fe=fe, tab_t=table(descs_t), tab_f=table(descs_f), dt=dt,
-                 ones={}, keep=(descs_t, descs_f))
+                 ones={}, keep=(descs_t, descs_f), wmsa=wmsa)
         self.prep[dt] = P
         return P
 
@@ -276,6 +287,11 @@ class Engine:
         ops.prep_weights(tt, nt, mt, L.BF16 if P["dt"] == torch.bfloat16 else L.F32)
         tf, nf, mf = P["tab_f"]
         ops.prep_weights(tf, nf, mf, L.F32)
+        p = self.params
+        for pre, wpk in P["wmsa"].items():
+            ops.wmsa_pack(p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"], p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"],
+                          p[pre + "attn.relative_position_bias_table"], p[pre + "norm1.weight"], p[pre + "norm1.bias"],
+                          p[pre + "norm2.weight"], p[pre + "norm2.bias"], wpk, p[pre + "attn.qkv.weight"].shape[1], HEADS, 8)
 
     # ------------------------------------------------------------------ public entry
     MAX_PLANS = 4      # each plan owns a full activation workspace (31 GB at B=8 @1024^2 bf16): least recently used goes
@@ -432,17 +448,29 @@ class Engine:
         ws, shift = self._block_geo(blk, H, W)
         xn1 = plan.buf(tag + ".xn1", (M, Cc))
         st1 = plan.buf(tag + ".st1", (M, 2), torch.float32)
-        ops.layernorm_fwd(x_in, p[pre + "norm1.weight"], p[pre + "norm1.bias"], xn1, st1, M, Cc)
-        qkv = plan.buf(tag + ".qkv", (M, 3 * Cc))
-        ops.gemm_nt([SegSpec(xn1)], w[pre + "attn.qkv.weight"], qkv, M, 3 * Cc, Cc, bias=p[pre + "attn.qkv.bias"])
-        ao = plan.buf(tag + ".ao", (M, Cc))
-        lse = plan.buf(tag + ".lse", (M, HEADS), torch.float32)
-        ops.window_attn_fwd(qkv, P["bias_t"][pre + "attn.relative_position_bias_table"], ao, lse, B, H, W, Cc, HEADS, ws, shift)
         xm = plan.buf(tag + ".xm", (M, Cc))
-        ops.gemm_nt([SegSpec(ao)], w[pre + "attn.proj.weight"], xm, M, Cc, Cc, bias=p[pre + "attn.proj.bias"], resid=x_in)
         xn2 = plan.buf(tag + ".xn2", (M, Cc))
         st2 = plan.buf(tag + ".st2", (M, 2), torch.float32)
-        ops.layernorm_fwd(xm, p[pre + "norm2.weight"], p[pre + "norm2.bias"], xn2, st2, M, Cc)
+        ao = plan.buf(tag + ".ao", (M, Cc))
+        wpk = P["wmsa"].get(pre) if (ws == 8 and H % 8 == 0 and W % 8 == 0) else None
+        fused = wpk is not None
+        if fused:
+            # LN1 + QKV + window attention + proj + residual + LN2 in ONE launch (csrc/wmsa_block.hip); training also writes the
+            # tensors the backward needs: q/k/v and the log-sum-exp in window-major order (sodt_window_attn_bwd_wm)
+            qkvw = plan.buf(tag + ".qkvw", (M // 64, HEADS, 3, 64, Cc // HEADS))
+            lsew = plan.buf(tag + ".lsew", (M // 64, HEADS, 64), torch.float32)
+            if plan.training:
+                ops.wmsa_block_fwd(x_in, wpk, xm, xn2, st1, st2, xn1, qkvw, lsew, ao, B, H, W, Cc, HEADS, ws, shift)
+            else:
+                ops.wmsa_block_fwd(x_in, wpk, xm, xn2, None, None, None, None, None, None, B, H, W, Cc, HEADS, ws, shift)
+        else:
+            ops.layernorm_fwd(x_in, p[pre + "norm1.weight"], p[pre + "norm1.bias"], xn1, st1, M, Cc)
+            qkv = plan.buf(tag + ".qkv", (M, 3 * Cc))
+            ops.gemm_nt([SegSpec(xn1)], w[pre + "attn.qkv.weight"], qkv, M, 3 * Cc, Cc, bias=p[pre + "attn.qkv.bias"])
+            lse = plan.buf(tag + ".lse", (M, HEADS), torch.float32)
+            ops.window_attn_fwd(qkv, P["bias_t"][pre + "attn.relative_position_bias_table"], ao, lse, B, H, W, Cc, HEADS, ws, shift)
+            ops.gemm_nt([SegSpec(ao)], w[pre + "attn.proj.weight"], xm, M, Cc, Cc, bias=p[pre + "attn.proj.bias"], resid=x_in)
+            ops.layernorm_fwd(xm, p[pre + "norm2.weight"], p[pre + "norm2.bias"], xn2, st2, M, Cc)
         xo = plan.buf(tag + ".xo", (M, Cc))
         if blk.mlp.linear:
             ha = plan.buf(tag + ".ha", (M, 4 * Cc))
@@ -462,7 +490,7 @@ class Engine:
             ops.gemm_nt(segs, w[pre + "mlp.conv1.weight"], cp, M, Cc, 4 * Cc, spatial=(H, W), bias=p[pre + "mlp.conv1.bias"],
                         gelu_out=ca)
             ops.gemm_nt([SegSpec(ca)], w[pre + "mlp.fc2.weight"], xo, M, Cc, Cc, bias=p[pre + "mlp.fc2.bias"], resid=xm)
-        plan.saved[tag] = dict(x_in=x_in, geo=(B, H, W, Cc, ws, shift))
+        plan.saved[tag] = dict(x_in=x_in, geo=(B, H, W, Cc, ws, shift), fused=fused)
         return xo
 
     def _block_bwd(self, plan, P, tag, blk, dY, dX):
@@ -474,7 +502,7 @@ class Engine:
         B, H, W, Cc, ws, shift = sv["geo"]
         M = B * H * W
         x_in = sv["x_in"]
-        xm, xn2, xn1, ao, qkv = b[tag + ".xm"], b[tag + ".xn2"], b[tag + ".xn1"], b[tag + ".ao"], b[tag + ".qkv"]
+        xm, xn2, xn1, ao = b[tag + ".xm"], b[tag + ".xn2"], b[tag + ".xn1"], b[tag + ".ao"]
         dxn = plan.buf(f"g.dxn.{Cc}", (M, Cc))
         dxm = plan.buf(f"g.dxm.{Cc}", (M, Cc))
         if blk.mlp.linear:
@@ -509,9 +537,13 @@ class Engine:
         dqkv = plan.buf(f"g.dqkv.{Cc}", (M, 3 * Cc))
         L2 = 2 * ws - 1
         dbt = plan.buf(f"g.dbt.{L2}", (HEADS, L2 * L2), torch.float32, zero=True)
-        scratch = plan.buf(f"g.attn_scratch.{Cc}", (M * (Cc + HEADS),), torch.float32, zero=True) if ws * ws > 64 else None
-        ops.window_attn_bwd(qkv, P["bias_t"][pre + "attn.relative_position_bias_table"], ao, dao, b[tag + ".lse"], dqkv, dbt,
-                            scratch, B, H, W, Cc, HEADS, ws, shift)
+        if sv["fused"]:
+            ops.window_attn_bwd_wm(b[tag + ".qkvw"], P["bias_t"][pre + "attn.relative_position_bias_table"], dao, b[tag + ".lsew"],
+                                   dqkv, dbt, B, H, W, Cc, HEADS, ws, shift)
+        else:
+            scratch = plan.buf(f"g.attn_scratch.{Cc}", (M * (Cc + HEADS),), torch.float32, zero=True) if ws * ws > 64 else None
+            ops.window_attn_bwd(b[tag + ".qkv"], P["bias_t"][pre + "attn.relative_position_bias_table"], ao, dao, b[tag + ".lse"], dqkv,
+                                dbt, scratch, B, H, W, Cc, HEADS, ws, shift)
         ops.transpose_f32(dbt, g[pre + "attn.relative_position_bias_table"], HEADS, L2 * L2, accumulate=2)
         ops.gemm_tn(dqkv, [SegSpec(xn1)], g[pre + "attn.qkv.weight"], M, 3 * Cc, Cc, dbias=g[pre + "attn.qkv.bias"])
         ops.gemm_nt([SegSpec(dqkv)], wT[pre + "attn.qkv.weight"], dxn, M, Cc, 3 * Cc)
