@@ -130,7 +130,10 @@ def main():
     if world > 1:
         ddp = importlib.import_module(PKG + ".ddp")
         ddp.attach(model, average=True)
-    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.937, nesterov=True)   # models/hyp.scratch.yaml
+    # Train.py:139-150,283: SGD(momentum 0.937, nesterov) over the two weight-decay groups + ModelEMA, here one fused kernel
+    O = importlib.import_module(PKG + ".optim")
+    ema = O.ModelEMA(model)
+    opt = O.FusedSGD(O.set_weight_decay(model), model=model, lr=0.01, momentum=0.937, nesterov=True, ema=ema)
     g = torch.Generator(device="cpu").manual_seed(2 + rank)                            # Train.py:72
     x_rgb = torch.rand(B, 3, S, S, generator=g).to(dev)
     x_ir = torch.rand(B, 3, S, S, generator=g).to(dev)
@@ -141,6 +144,7 @@ def main():
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
+        ema.update(model)
         return loss
 
     def barrier():
@@ -196,7 +200,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"SRyolo_MF.yaml (model.yaml graph), batch {B}/GPU @ {S}x{S} RGB+IR, fwd + hand-written bwd "
-                                   f"+ SGD step, loss = mean(pred^2), random-init weights", "global_batch": world * B,
+                                   f"+ fused SGD-nesterov/weight-decay + EMA step, loss = mean(pred^2), random-init weights", "global_batch": world * B,
                        "parallelism": f"dp{world}"},
             "model_tflops": round(img_s * FLOP_PER_IMG_1024 * (S / 1024) ** 2 / 1e12, 1),
             # the kernel north_star prices at the MFMA roofline (fused AI 448 flop/B in inference form; the training launch also

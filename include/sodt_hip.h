@@ -257,6 +257,19 @@ typedef struct {
 } sodt_prep_desc;
 int sodt_prep_weights(const sodt_prep_desc* table_dev, int n, int max_elems, int dtype, sodt_stream_t st);
 
+/* Fused optimizer step over the flat f32 parameter / gradient / momentum / EMA buffers (csrc/optim.hip): what the reference
+ * does with torch.optim.SGD(momentum, nesterov) over the weight-decay groups of basics/optimizer.py:35-49 (Train.py:145-150,
+ * :448-450), ModelEMA.update (basics/utils/torch_utils.py:291-301) and the cast of the masters to the run dtype, in one
+ * streaming launch.  All buffers hold n_elems f32 (16-byte aligned, n_elems % 4 == 0); every 4-element chunk belongs to
+ * one parameter and group_of_chunk[chunk] (device bytes, nullable = all group 0) picks its hyper-parameters
+ * lr / momentum / weight_decay[group] (host arrays of ngroups <= 4); 255 = not trained (cast / EMA only).
+ *   d = g*grad_scale + wd*p;  m = momentum*m + d;  u = nesterov ? d + momentum*m : m;  p -= lr*u
+ *   ema = ema*ema_decay + (1-ema_decay)*p (ema nullable);  p_cast = (cast_dtype) p (p_cast nullable). */
+int sodt_sgd_ema_step(float* p, const float* g, float* mom, float* ema, void* p_cast, int cast_dtype,
+                      const unsigned char* group_of_chunk, long n_elems, int ngroups, const float* lr,
+                      const float* momentum, const float* weight_decay, int nesterov, float grad_scale,
+                      float ema_decay, sodt_stream_t st);
+
 /* hipMemsetAsync(p, 0, bytes) on the stream (statistics / gradient accumulators) */
 int sodt_memset_zero(void* p, long bytes, sodt_stream_t st);
 

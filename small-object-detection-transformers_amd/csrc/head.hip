@@ -228,6 +228,30 @@ __global__ __launch_bounds__(256) void prep_kernel(const sodt_prep_desc* __restr
   const int e0 = dims[d.p0], e1 = dims[d.p1], e2 = dims[d.p2];
   const long total = (long)e0 * e1 * e2;
   T* dst = (T*)d.dst;
+  if (d.d2 == 1 && d.p0 == 1 && d.p2 == 0) {
+    // plain 2-D transpose dst[k][n] = src[n][k] (every wT of an nn.Linear / 1x1 Conv2d): 32 x 32 tiles through LDS so that
+    // both the f32 reads and the run-dtype writes are coalesced (the generic loop below reads with stride K)
+    __shared__ float tile[32][33];
+    const int N = d.d0, K = d.d1;
+    const int tn = (N + 31) >> 5, tk = (K + 31) >> 5;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tIdx = blockIdx.x; tIdx < tn * tk; tIdx += gridDim.x) {
+      const int n0 = (tIdx / tk) << 5, k0 = (tIdx % tk) << 5;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + ty + 8 * j, k = k0 + tx;
+        tile[ty + 8 * j][tx] = (n < N && k < K) ? d.src[(long)n * K + k] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + ty + 8 * j, n = n0 + tx;
+        if (k < K && n < N) dst[(long)k * d.dst_ld + n] = from_f<T>(tile[tx][ty + 8 * j]);
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int i2 = (int)(i % e2); const long r = i / e2;
     const int i1 = (int)(r % e1); const int i0 = (int)(r / e1);

@@ -129,6 +129,7 @@ class Engine:
         self.probes_bwd: Optional[dict] = None
         self.prep: Dict[torch.dtype, dict] = {}
         self._build_grad_buffer()
+        self._build_param_buffer()
         # anchor that makes the autograd node require grad even if the caller froze everything else
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
         self.ddp = None     # set by ddp.attach()
@@ -171,7 +172,7 @@ class Engine:
         offs, tot = {}, 0
         for n in self.grad_order:
             offs[n] = tot
-            tot += (self.params[n].numel() + 3) // 4 * 4      # keep every view 16-byte aligned
+            tot += (self.params[n].numel() + 7) // 8 * 8      # every view 16-byte aligned in f32 AND in the bf16 mirror
         self.flat_grad = torch.zeros(tot, device=self.dev, dtype=torch.float32)
         self.g: Dict[str, torch.Tensor] = {}
         for n in self.grad_order:
@@ -190,6 +191,32 @@ class Engine:
         self.g_fe_b = self.flat_grad[offs[E + "channel_embed_r.proj.bias"]:][: 4 * 48]
         self.g_fe_g = self.flat_grad[offs[E + "chan_block.norm1.weight"]:][: 4 * 48]
         self.g_fe_be = self.flat_grad[offs[E + "chan_block.norm1.bias"]:][: 4 * 48]
+
+    def _build_param_buffer(self):
+        """Re-home every parameter into ONE flat f32 buffer with the layout of the gradient buffer (`p.data` become views),
+        so that the optimizer step, the EMA and the cast to the run dtype are one streaming kernel over
+        (flat_param, flat_grad, momentum, ema) - optim.FusedSGD, csrc/optim.hip - instead of 273 small launches."""
+        self.flat_param = torch.zeros_like(self.flat_grad)
+        with torch.no_grad():
+            for n in self.grad_order:
+                p = self.params[n]
+                v = self.flat_param[self.grad_offsets[n]: self.grad_offsets[n] + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+        self.flat_cast: Dict[torch.dtype, torch.Tensor] = {}     # run-dtype mirror of flat_param (bf16 path)
+        self.param_cast_fresh = False     # True: flat_cast == cast(flat_param) (set by optim.FusedSGD.step, cleared by invalidate_params)
+
+    def invalidate_params(self):
+        """Tell the engine the f32 masters were changed by something other than optim.FusedSGD (load_state_dict, a torch
+        optimizer, manual edits): the run-dtype mirror is re-cast at the next forward."""
+        self.param_cast_fresh = False
+
+    def _check_param_views(self):
+        for n in self.grad_order:
+            p = self.params[n]
+            if p.data_ptr() != self.flat_param.data_ptr() + 4 * self.grad_offsets[n]:
+                raise RuntimeError(f"{n} no longer lives in the engine's flat parameter buffer (model.to()/.float()/.half() after the "
+                                   "first forward re-allocates parameters): rebuild the engine with model._engine = None")
 
     def _claim_grads(self):
         """Make param.grad the views of the flat buffer; zero it when the grads were reset."""
@@ -222,19 +249,34 @@ class Engine:
             d.dst_ld = dst_ld
             desc_list.append(d)
 
+        # run-dtype mirror of the whole parameter buffer: every weight whose GEMM layout [N][K] IS its storage layout (all
+        # nn.Linear and 1x1 Conv2d weights, pos_embed) is a VIEW of it - no per-step permute / cast launch for them; f32 runs
+        # view the masters themselves
+        if dt == torch.float32:
+            mirror = self.flat_param
+        else:
+            mirror = self.flat_cast.get(dt)
+            if mirror is None:
+                mirror = self.flat_cast[dt] = torch.zeros_like(self.flat_param, dtype=dt)
+
+        def mview(n, shape):
+            o = self.grad_offsets[n]
+            return mirror[o: o + self.params[n].numel()].view(shape)
         for n, p in self.params.items():
             if p.dim() < 2 or "relative_position_bias_table" in n or "channel_embed" in n:
                 continue
             if n == E + "pos_embed":
                 t = p.shape[1]
-                w[n] = torch.zeros(t * t, 192, device=dev, dtype=dt)
-                add(descs_t, p, w[n], (t * t, 192, 1), (0, 1, 2), 192)
+                w[n] = mview(n, (t * t, 192))
                 continue
             N, K = p.shape[0], p.shape[1]
             taps = p.numel() // (N * K)
             Np = (N + 15) // 16 * 16 if n.startswith("detect.8.") else N     # Detect: 39 -> 48 zero-padded
-            w[n] = torch.zeros(Np, taps * K, device=dev, dtype=dt)           # [N][tap*K + k]
-            add(descs_t, p, w[n], (N, K, taps), (0, 2, 1), taps * K)
+            if taps == 1 and Np == N:
+                w[n] = mview(n, (N, K))
+            else:
+                w[n] = torch.zeros(Np, taps * K, device=dev, dtype=dt)       # [N][tap*K + k]
+                add(descs_t, p, w[n], (N, K, taps), (0, 2, 1), taps * K)
             wT[n] = torch.zeros(K, taps * Np, device=dev, dtype=dt)          # [K][tap*N + n]
             add(descs_t, p, wT[n], (N, K, taps), (1, 2, 0), taps * Np)
         # Linear MLPs on the bf16 path keep only the activation: the backward GEMM recomputes the pre-activation from
@@ -353,6 +395,10 @@ class Engine:
         B, S = plan.B, plan.S
         t = S // 4
         plan.gen += 1          # the saved activations of an earlier forward on this plan are gone (see _EngineFn.backward)
+        # (0) run-dtype mirror of the masters: written by the fused optimizer step; re-cast here when anything else may have
+        #     changed them (live call: the decision is per step)
+        if plan.dt != torch.float32 and not self.param_cast_fresh:
+            ops.cast(self.flat_param, self.flat_cast[plan.dt], self.flat_param.numel())
         # (1) parameter preparation (recorded)
         if plan.fwd_pre is None:
             with ops.Recorder() as rec:

@@ -384,6 +384,15 @@ def batch_sum(d, out, B, RC):
     _launch("sodt_batch_sum", _p(d), _p(out), B, RC, dt_code(d))
 
 
+def sgd_ema_step(p, g, mom, ema, p_cast, group_of_chunk, lr, momentum, weight_decay, nesterov, grad_scale=1.0, ema_decay=0.0):
+    """One fused SGD(+nesterov, weight decay groups) + EMA + run-dtype cast pass over the flat buffers (csrc/optim.hip)."""
+    ng = len(lr)
+    arr = lambda v: (C.c_float * ng)(*[float(x) for x in v])
+    code = L.F32 if p_cast is None else dt_code(p_cast)
+    _launch("sodt_sgd_ema_step", _p(p), _p(g), _p(mom), _p(ema), _p(p_cast), code, _p(group_of_chunk), p.numel(), ng,
+            arr(lr), arr(momentum), arr(weight_decay), int(bool(nesterov)), C.c_float(grad_scale), C.c_float(ema_decay))
+
+
 def gemm_set_variant(v) -> None:
     """0/False: automatic; 1/True: force the K-loop tile kernel; 2: force the A-stationary kernel (tests)."""
     _lib.sodt_gemm_set_variant(int(v))

@@ -1,0 +1,113 @@
+"""optim.FusedSGD + optim.ModelEMA (one fused kernel over the flat buffers, csrc/optim.hip) against torch.optim.SGD with the
+reference's two weight-decay groups (basics/optimizer.py:35-49, Train.py:145-150) followed by the reference's ModelEMA
+update loop (basics/utils/torch_utils.py:291-301, restated below), three steps with per-group learning rates that change
+every step as the warm-up of Train.py:375-385 does."""
+import copy
+import importlib
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+PKG = "small-object-detection-transformers_amd"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(dev):
+    import yaml
+    M = importlib.import_module(PKG + ".model")
+    cfg = yaml.safe_load(open(os.path.join(ROOT, PKG, "configs", "SRyolo_MF.yaml")))
+    cfg["backbone"][0][3][0] = 128
+    torch.manual_seed(0)
+    m = M.Model(cfg, input_mode="RGB+IR", ch_steam=3, ch=128, nc=8).to(dev).train()
+    m.compute_dtype = torch.float32
+    return m
+
+
+class _RefEMA:          # torch_utils.py:283-301
+    def __init__(self, model, decay=0.9999):
+        self.ema = copy.deepcopy(model).eval()
+        self.updates = 0
+        self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+
+    def update(self, model):
+        with torch.no_grad():
+            self.updates += 1
+            d = self.decay(self.updates)
+            msd = model.state_dict()
+            for k, v in self.ema.state_dict().items():
+                if v.dtype.is_floating_point:
+                    v *= d
+                    v += (1. - d) * msd[k].detach()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_sgd_ema_matches_torch(dev, dt):
+    O = importlib.import_module(PKG + ".optim")
+    ma, mb = _build(dev), _build(dev)
+    ma.compute_dtype = mb.compute_dtype = dt
+    ema_a = O.ModelEMA(ma)
+    ema_b = _RefEMA(mb)
+    opt_a = O.FusedSGD(O.set_weight_decay(ma), model=ma, lr=0.01, momentum=0.937, nesterov=True, ema=ema_a)
+    opt_b = torch.optim.SGD(O.set_weight_decay(mb), lr=0.01, momentum=0.937, nesterov=True)
+    g = torch.Generator().manual_seed(5)
+    x, ir = torch.rand(2, 3, 128, 128, generator=g).to(dev), torch.rand(2, 3, 128, 128, generator=g).to(dev)
+    for step in range(3):
+        for opt in (opt_a, opt_b):                   # warm-up style per-group schedules (Train.py:375-385)
+            opt.param_groups[0]["lr"] = 0.002 * (step + 1)
+            opt.param_groups[1]["lr"] = 0.1 - 0.03 * step
+            for gr in opt.param_groups:
+                gr["momentum"] = 0.8 + 0.04 * step
+        # one forward / backward (model A); model B steps on a COPY of A's gradients and running statistics, so that the
+        # comparison is the optimizer + EMA arithmetic and not the run-to-run summation order of the gradient kernels
+        pred, _ = ma(x, ir, "RGB+IR")
+        pred[0].float().square().mean().backward()
+        pa = dict(ma.named_parameters())
+        for k, p in mb.named_parameters():
+            p.grad = pa[k].grad.detach().clone()
+        ba = dict(ma.named_buffers())
+        with torch.no_grad():
+            for k, bfr in mb.named_buffers():
+                bfr.copy_(ba[k])
+        for m, opt, ema in ((ma, opt_a, ema_a), (mb, opt_b, ema_b)):
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            ema.update(m)
+        torch.cuda.synchronize()
+        tol = 2e-6
+        sa, sb = ma.state_dict(), mb.state_dict()
+        ea, eb = ema_a.ema.state_dict(), ema_b.ema.state_dict()
+        for k in sa:
+            if not sa[k].dtype.is_floating_point:
+                continue
+            s = float(sb[k].abs().max()) + 1e-5
+            assert float((sa[k] - sb[k]).abs().max()) <= tol * s, f"step {step}: parameter {k}"
+            s = float(eb[k].abs().max()) + 1e-5
+            assert float((ea[k] - eb[k]).abs().max()) <= tol * s, f"step {step}: EMA of {k}"
+    assert ema_a.updates == 3
+    # the EMA module is an ordinary Model: it evaluates through its own engine with the averaged weights
+    ema_a.ema.compute_dtype = torch.float32
+    ema_b.ema.compute_dtype = torch.float32
+    with torch.no_grad():
+        za = ema_a.ema(x, ir, "RGB+IR")[0]
+        zb = ema_b.ema(x, ir, "RGB+IR")[0]
+    assert float((za - zb).abs().max()) <= 2e-3 * float(zb.abs().max())
+    # the bf16 mirror written by the fused step is what a re-cast of the masters gives
+    if dt == torch.bfloat16:
+        eng = ma._get_engine()
+        assert eng.param_cast_fresh and torch.equal(eng.flat_cast[dt], eng.flat_param.to(dt))
+
+
+def test_fused_sgd_skips_without_gradients_and_checks_views(dev):
+    O = importlib.import_module(PKG + ".optim")
+    m = _build(dev)
+    opt = O.FusedSGD(m.parameters(), model=m, lr=0.1)
+    before = m._get_engine().flat_param.clone()
+    opt.step()                                          # no backward yet: torch.optim.SGD would skip every parameter
+    assert torch.equal(before, m._get_engine().flat_param)
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
