@@ -1,0 +1,127 @@
+"""Per-kernel roofline table of one training step: every recorded launch of the forward and backward
+plans is timed live with HIP events on the launch stream (3 repetitions), its ALGORITHMIC bytes and flops are derived from
+its own arguments, and launches are grouped by (entry point, shape).  Bounds use the spec peaks of
+/opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM, 2.5 PFLOP/s dense bf16.   frac = max(bytes / 8e12, flops / 2.5e15) / time.
+
+  python tools/roofline_table.py [out.md]        (B=8 @1024^2 bf16 by default: env B, S)
+"""
+import collections, importlib, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+L = importlib.import_module(bench.PKG + "._lib")
+HBM, MFMA = 8e12, 2.5e15
+ES = 2          # bf16
+
+
+def unwrap(a):
+    return a._obj if hasattr(a, "_obj") else a
+
+
+def val(a):
+    a = unwrap(a)
+    return a.value if hasattr(a, "value") else a
+
+
+def cost(name, args):
+    """(shape string, algorithmic bytes, flops) of one launch."""
+    if name == "sodt_gemm_nt":
+        g = unwrap(args[0])
+        kin, seen = 0.0, set()
+        for k in range(g.a.nseg):
+            s = g.a.s[k]
+            if g.a.spatial and s.p in seen:
+                continue
+            seen.add(s.p)
+            kin += s.klen / ((s.mul * s.mul) if (g.a.spatial and s.shr) else 1)
+        nout = 2 if g.flags & 4 else 1
+        extra = (1 if g.flags & 2 else 0) + (1 if g.flags & 8 else 0)
+        oes = 4 if g.flags & (64 | 128) else ES
+        return (f"M={g.M} N={g.N} K={g.K} flags={g.flags}", g.M * (kin * ES + g.N * (nout * oes + extra * ES)) + g.N * g.K * ES,
+                2.0 * g.M * g.N * g.K)
+    if name == "sodt_gemm_tn":
+        g = unwrap(args[0])
+        kin, seen = 0.0, set()
+        for k in range(g.x.nseg):
+            s = g.x.s[k]
+            if g.x.spatial and s.p in seen:
+                continue
+            seen.add(s.p)
+            kin += s.klen
+        return (f"M={g.M} N={g.N} K={g.K} dW", g.M * (kin + g.N) * ES + 2.0 * g.N * g.K * 4, 2.0 * g.M * g.N * g.K)
+    if name == "sodt_wmsa_block_fwd":
+        B, H, W, C = (val(args[i]) for i in (10, 11, 12, 13))
+        T = B * H * W
+        return (f"T={T} C={C} train", T * (9 * C * ES + 12 * 4 + 16), 8.0 * T * C * C + 4.0 * T * 64 * C)
+    if name in ("sodt_window_attn_fwd", "sodt_window_attn_bwd", "sodt_window_attn_bwd_wm"):
+        o = {"sodt_window_attn_fwd": 4, "sodt_window_attn_bwd": 8, "sodt_window_attn_bwd_wm": 6}[name]
+        B, H, W, C, heads, ws = (val(args[o + i]) for i in range(6))
+        T, N = B * H * W, ws * ws
+        if name == "sodt_window_attn_fwd":
+            return (f"T={T} C={C} ws={ws} fwd", T * (4 * C * ES + heads * 4), 4.0 * T * N * C)
+        return (f"T={T} C={C} ws={ws} bwd", T * (8 * C * ES + heads * 4), 10.0 * T * N * C)       # S, dP, dV, dK, dQ
+    if name == "sodt_layernorm_fwd":
+        M, C = val(args[5]), val(args[6])
+        return (f"M={M} C={C}", M * (2 * C * ES + 8), 0.0)
+    if name == "sodt_layernorm_bwd":
+        M, C = val(args[8]), val(args[9])
+        nin = 3 if args[4] else 2
+        return (f"M={M} C={C}", M * ((nin + 1) * C * ES + 8), 0.0)
+    return ("", 0.0, 0.0)
+
+
+def main():
+    B, S = int(os.environ.get("B", 8)), int(os.environ.get("S", 1024))
+    dev = torch.device("cuda:0")
+    model = bench.build_model(S, dev, torch.bfloat16)
+    x = torch.rand(B, 3, S, S, device=dev); ir = torch.rand(B, 3, S, S, device=dev)
+
+    def step():
+        pred, _ = model(x, ir, "RGB+IR"); pred[0].float().square().mean().backward()
+        for p in model.parameters():
+            p.grad = None
+    for _ in range(3):
+        step()
+    eng = model._get_engine(); plan = eng.plans[(B, S, torch.bfloat16, True)]
+    groups = collections.OrderedDict()
+    total = 0.0
+    for which, calls in (("fwd", plan.fwd_main), ("bwd", plan.bwd_main)):
+        evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in range(len(calls))}
+        acc = collections.defaultdict(float)
+        for rep in range(3):
+            setattr(eng, "probes_" + which, evs)
+            step(); torch.cuda.synchronize()
+            setattr(eng, "probes_" + which, None)
+            for i in range(len(calls)):
+                acc[i] += evs[i][0].elapsed_time(evs[i][1]) / 3
+        for i, (fn, args, name, tag) in enumerate(calls):
+            shape, byt, fl = cost(name, args)
+            g = groups.setdefault((name.replace("sodt_", ""), shape), [0, 0.0, 0.0, 0.0, set()])
+            g[0] += 1; g[1] += acc[i]; g[2] += byt; g[3] += fl; g[4].add(tag.split(".")[0])
+            total += acc[i]
+    lines = [f"# Per-kernel roofline table, one training step, B={B} @{S}x{S} bf16 (tools/roofline_table.py)", "",
+             f"Sum of the recorded launches: {total:.2f} ms per step (live launches - front end, Detect, optimizer, prep - are outside the "
+             "recorded plans: ~1.5 ms).  HIP events on the launch stream, mean of 3 steps.  bytes / flops are ALGORITHMIC (each operand "
+             "crosses HBM once); frac = max(bytes / 8 TB/s, flops / 2.5 PFLOP/s) / time.", "",
+             "| entry point | shape | launches | ms/step | % | alg. MB / launch | GFLOP / launch | GB/s | TFLOP/s | bound | frac |",
+             "|---|---|---|---|---|---|---|---|---|---|---|"]
+    cum = 0.0
+    for (name, shape), (n, ms, byt, fl, tags) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+        t = ms / n * 1e-3
+        bb, fb = byt / n / HBM, fl / n / MFMA
+        frac = max(bb, fb) / t if t > 0 and (byt or fl) else float("nan")
+        cum += ms
+        lines.append(f"| {name} | {shape} ({','.join(sorted(tags))}) | {n} | {ms:.3f} | {100 * ms / total:.1f} | {byt / n / 1e6:.0f} | {fl / n / 1e9:.1f} | "
+                     f"{byt / n / t / 1e9 if t else 0:.0f} | {fl / n / t / 1e12 if t else 0:.0f} | {'mfma' if fb > bb else 'hbm'} | {frac:.3f} |")
+        if cum >= 0.93 * total:
+            break
+    lines.append("")
+    lines.append(f"The rows above cover {100 * cum / total:.0f} % of the recorded step time.")
+    out = "\n".join(lines)
+    print(out)
+    if len(sys.argv) > 1:
+        open(sys.argv[1], "w").write(out + "\n")
+
+
+main()

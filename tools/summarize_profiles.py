@@ -1,46 +1,76 @@
-"""gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) -> profiles/<tag>_kernel_stats.csv, _summary.md, _traffic.json"""
-import collections, csv, glob, json, os, shutil, sys
+"""gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) -> profiles/<tag>_kernel_stats.csv, <tag>_summary.md,
+<tag>_wmsa_traffic.json (HBM bytes per launch of the roofline kernel, read by bench.py when the kernel source is unchanged)
+and <tag>_mfma_util.md (matrix-pipe utilisation of the top kernels)."""
+import collections, csv, glob, hashlib, json, os, shutil, sys
 tag = sys.argv[1]
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 st = glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0]
 shutil.copy(st, f"profiles/{tag}_kernel_stats.csv")
 rows = list(csv.DictReader(open(st)))
-line = [l for l in open(f"{src}/stats.log") if l.startswith('{"metric"')][0]
-bench = json.loads(line)
+bench = json.loads([l for l in open(f"{src}/stats.log") if l.startswith('{"metric"')][0])
 steps = bench["steps"] + max(bench["warmup"], 2)
-KEYS = ("gemm_nt3_kernelILi257E", "gemm_nt3_kernel<257>")
-KEY = "gemm_nt3_kernel<257>"       # pipelined bf16 NT kernel, flags BIAS|GELU: every linear fc1; the stage-1 launches
-                                   # (M=524288, N=768, K=192) are the longest of them, selected by duration below
-def dispatches(path, name=None):
-    """(duration_ns, counter_value) of every dispatch of KEY in a rocprofv3 CSV (kernel trace or counter collection)."""
+KEY = "wmsa_block_kernelIDF16bLi4ELi2ELb1E"      # bf16, 4 waves, double-buffered stages, save-for-backward
+
+
+def dispatches(path, key, name=None):
     out = []
     for r in csv.DictReader(open(path)):
-        if any(k_ in r["Kernel_Name"] for k_ in KEYS) and (name is None or r["Counter_Name"] == name):
-            out.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"]), float(r.get("Counter_Value", 0) or 0)))
+        if key in r["Kernel_Name"] and (name is None or r.get("Counter_Name") == name):
+            out.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) if "End_Timestamp" in r else 0.0,
+                        float(r.get("Counter_Value", 0) or 0)))
     return out
-def stage1(ds):
-    mx = max(d for d, _ in ds)
-    return [(d, v) for d, v in ds if d >= 0.8 * mx]
-fe = stage1(dispatches(glob.glob(f"{src}/fetch/*/*counter_collection.csv")[0], "FETCH_SIZE"))
-wr = stage1(dispatches(glob.glob(f"{src}/write/*/*counter_collection.csv")[0], "WRITE_SIZE"))
-kt = stage1(dispatches(glob.glob(f"{src}/stats/*/*kernel_trace.csv")[0]))
-k = KEY
+
+
+fe = dispatches(glob.glob(f"{src}/fetch/*/*counter_collection.csv")[0], KEY, "FETCH_SIZE")
+wr = dispatches(glob.glob(f"{src}/write/*/*counter_collection.csv")[0], KEY, "WRITE_SIZE")
+kt = dispatches(glob.glob(f"{src}/stats/*/*kernel_trace.csv")[0], KEY)
 fetch_kb, write_kb = sum(v for _, v in fe) / len(fe), sum(v for _, v in wr) / len(wr)
 avg_ns = sum(d for d, _ in kt) / len(kt)
+flops = bench["roofline"]["flops_per_launch"]
+ksrc = "small-object-detection-transformers_amd/csrc/wmsa_block.hip"
 traffic = {
-    "kernel": k + " (stage-1 fc1 launches, selected by duration)", "launches_sampled": len(fe),
+    "kernel": "wmsa_block_kernel<bf16, 4 waves, 2 stages, save-for-backward> (stage-1 launches of bench.py)", "launches_sampled": len(fe),
+    "kernel_source_sha256": hashlib.sha256(open(ksrc, "rb").read()).hexdigest(),
     "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
-    "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane streaming reads -> x2; WRITE_SIZE exact; separate --pmc passes",
+    "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane streaming reads -> x2; "
+                  "WRITE_SIZE exact; separate --pmc passes",
     "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
-    "rocprof_avg_launch_ms": avg_ns / 1e6, "bench_line": bench,
+    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes"],
+    "rocprof_avg_launch_ms": avg_ns / 1e6, "launches_in_trace": len(kt),
+    "mfma_frac_from_trace": flops / (avg_ns * 1e-9) / 2.5e15, "bench_line": bench,
 }
-json.dump(traffic, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+json.dump(traffic, open(f"profiles/{tag}_wmsa_traffic.json", "w"), indent=1)
 with open(f"profiles/{tag}_summary.md", "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {bench['steps']} --warmup {bench['warmup']}` ({tag})\n\n")
     f.write(f"{bench['value']} img/s, {bench['ms_per_step']} ms/step; totals over the {steps} traced steps.\n\n| kernel | calls | ms/step | avg us | % |\n|---|---|---|---|---|\n")
-    for r in rows[:22]:
-        f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6/steps:.2f} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |\n")
-    f.write(f"\nRoofline kernel (stage-1 fc1 = the longest launches of `{KEY}`): rocprof kernel-trace average {avg_ns/1e3:.1f} us; HBM traffic per launch "
-            f"{traffic['hbm_bytes_per_launch']/1e6:.0f} MB (FETCH_SIZE {fetch_kb:.0f} KB x2 + WRITE_SIZE {write_kb:.0f} KB) vs 1007 MB algorithmic.\n")
-print(json.dumps(traffic)[:300])
+    for r in rows[:24]:
+        f.write(f"| `{r['Name'][:100]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6/steps:.2f} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |\n")
+    f.write(f"\nRoofline kernel (`wmsa_block_kernel<bf16, save>`): kernel-trace average {avg_ns/1e3:.1f} us over {len(kt)} launches = "
+            f"{flops/(avg_ns*1e-9)/1e12:.1f} TFLOP/s = {traffic['mfma_frac_from_trace']:.4f} of 2.5 PFLOP/s (bench.py's live HIP-event figure: "
+            f"{bench['roofline']['avg_launch_ms']*1e3:.1f} us, frac {bench['roofline']['frac']}); HBM traffic per launch "
+            f"{traffic['hbm_bytes_per_launch']/1e6:.0f} MB (FETCH_SIZE {fetch_kb:.0f} KB x2 + WRITE_SIZE {write_kb:.0f} KB) vs "
+            f"{traffic['algorithmic_bytes_per_launch']/1e6:.0f} MB algorithmic.\n")
+# ---- MFMA utilisation of the top kernels
+mf = glob.glob(f"{src}/mfma/*/*counter_collection.csv")
+if mf:
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(mf[0])):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    top = [r["Name"] for r in rows[:12]]
+    with open(f"profiles/{tag}_mfma_util.md", "w") as f:
+        f.write(f"# Matrix-pipe utilisation per kernel ({tag}): rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE\n\n"
+                "MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): GRBM_GUI_ACTIVE sums the 8 XCDs "
+                "(MI355X_MICROARCH.md, DVFS section), SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs.\n\n"
+                "| kernel | launches | MFMA busy cycles / launch | GUI active / 8 | MFMA util |\n|---|---|---|---|---|\n")
+        for name in top:
+            key = next((k for k in agg if k[:60] == name[:60]), None)
+            if key is None:
+                continue
+            c = agg[key]
+            if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
+                continue
+            mb = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+            ga = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"]) / 8
+            f.write(f"| `{name[:90]}` | {len(c['GRBM_GUI_ACTIVE'])} | {mb:.3g} | {ga:.3g} | {mb / (1024 * ga) if ga else 0:.3f} |\n")
+print(json.dumps({k: v for k, v in traffic.items() if k != "bench_line"})[:600])
