@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--loss", default="yolo", choices=["yolo", "mse"],
+                    help="yolo: the reference's ComputeLoss (CIoU + BCE, device kernels) on fixed synthetic targets; mse: mean(pred^2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -138,9 +140,20 @@ def main():
     x_rgb = torch.rand(B, 3, S, S, generator=g).to(dev)
     x_ir = torch.rand(B, 3, S, S, generator=g).to(dev)
 
+    # 32 boxes per image, class ~U{0..7}, centre ~U(0.05, 0.95), size ~U(0.01, 0.05), seed 0
+    compute_loss = None
+    if a.loss == "yolo":
+        LS = importlib.import_module(PKG + ".loss")
+        model.hyp, model.gr, model.nc = dict(LS.DEFAULT_HYP), 1.0, 8
+        compute_loss = LS.ComputeLoss(model)
+        targets = LS.synthetic_targets(B, 32, 8, seed=0).to(dev)
+
     def step():
         pred, _ = model(x_rgb, x_ir, "RGB+IR")
-        loss = pred[0].float().square().mean()
+        if compute_loss is not None:
+            loss = compute_loss(pred, targets)[0] * world      # Train.py:418,440
+        else:
+            loss = pred[0].float().square().mean()
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
@@ -200,7 +213,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"SRyolo_MF.yaml (model.yaml graph), batch {B}/GPU @ {S}x{S} RGB+IR, fwd + hand-written bwd "
-                                   f"+ fused SGD-nesterov/weight-decay + EMA step, loss = mean(pred^2), random-init weights", "global_batch": world * B,
+                                   f"+ fused SGD-nesterov/weight-decay + EMA step, loss = {'YOLOv5 ComputeLoss (CIoU + BCE, device kernels), 32 synthetic boxes/image' if a.loss == 'yolo' else 'mean(pred^2)'}, random-init weights", "global_batch": world * B,
                        "parallelism": f"dp{world}"},
             "model_tflops": round(img_s * FLOP_PER_IMG_1024 * (S / 1024) ** 2 / 1e12, 1),
             # the kernel north_star prices at the MFMA roofline (fused AI 448 flop/B in inference form; the training launch also

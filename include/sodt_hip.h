@@ -270,6 +270,18 @@ int sodt_sgd_ema_step(float* p, const float* g, float* mom, float* ema, void* p_
                       const float* momentum, const float* weight_decay, int nesterov, float grad_scale,
                       float ema_decay, sodt_stream_t st);
 
+/* ComputeLoss.__call__ + build_targets (basics/utils/loss.py:116-224) with bbox_iou(CIoU) (basics/utils/general.py:347-389)
+ * for the single detection layer of models/model.yaml: loss values and d(loss * batch) / d pred in one call.
+ * pred f32 (B, na, ny, nx, 5+nc) contiguous; targets f32 (nt, 6) = (image, class, x, y, w, h) normalised (device);
+ * anchors f32 (na, 2) in grid units (Detect.anchors[0]); hyper-parameters as in models/hyp.scratch.yaml (box, cls,
+ * cls_pw, obj, obj_pw, anchor_t) and model.gr.  dpred f32 like pred; out4 = (loss * B, lbox, lobj, lcls) as loss.py:163.
+ * Duplicate cells take the objectness target of the LAST matching candidate in the reference's order (CPU index_put).
+ * ws: scratch of sodt_yolo_loss_workspace_bytes(B*na*ny*nx, nt, nc) bytes.  nc <= 32, na <= 8. */
+int sodt_yolo_loss_workspace_bytes(long ncells, int nt, int nc, size_t* bytes);
+int sodt_yolo_loss(const float* pred, const float* targets, int nt, const float* anchors, int B, int na, int ny, int nx,
+                   int nc, float h_box, float h_cls, float cls_pw, float h_obj, float obj_pw, float anchor_t, float gr,
+                   void* ws, size_t ws_bytes, float* dpred, float* out4, sodt_stream_t st);
+
 /* hipMemsetAsync(p, 0, bytes) on the stream (statistics / gradient accumulators) */
 int sodt_memset_zero(void* p, long bytes, sodt_stream_t st);
 

@@ -273,14 +273,59 @@ def nms_goldens(out):
     print("[pin] wrote nms.pt")
 
 
+def loss_goldens(out):
+    """Run the reference's own ComputeLoss (basics/utils/loss.py:90-224, float32 as in training) on fixed head outputs and
+    targets, pin the oracle's compute_loss against it and store inputs + outputs + d(loss)/d(pred)."""
+    LM = importlib.import_module("reference.basics.utils.loss")
+
+    class _Det:
+        pass
+
+    class _M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+    m, det = _M(), _Det()
+    det.nl, det.na, det.nc, det.stride = 1, 3, 8, torch.tensor([4.])
+    det.anchors = torch.tensor([[[10., 13.], [16., 30.], [33., 23.]]]) / 4          # models/model.yaml:8, model.py:131
+    m.detect, m.hyp, m.gr = [det], dict(R.LOSS_HYP), 1.0
+    cl = LM.ComputeLoss(m)
+    cases = []
+    for seed, (B, t, per) in enumerate([(2, 16, 12), (1, 32, 40), (2, 16, 0), (2, 8, 30)]):     # 30 boxes on 8x8: duplicate cells
+        torch.manual_seed(100 + seed)
+        pred = torch.randn(B, 3, t, t, 13, requires_grad=True)
+        tg = R.synthetic_targets(B, per, 8, seed) if per else torch.zeros(0, 6)
+        if (B, t) == (2, 8):
+            tg[:, 4:6] *= 8.0                                                      # boxes large enough for the 8x8 grid's anchors
+        ref = cl([pred], tg)
+        ref[0].backward()
+        dref = pred.grad.clone()
+        pred.grad = None
+        mine = R.compute_loss(pred, tg, det.anchors[0])
+        mine[0].backward()
+        dl = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(ref, mine))
+        dg = maxdiff(dref, pred.grad)
+        print(f"[pin] ComputeLoss B={B} grid {t} targets {tg.shape[0]}: loss {float(ref[0]):.5f} value diff {dl:.2e} grad diff {dg:.2e}")
+        assert dl < 1e-5 and dg < 1e-6
+        cases.append(dict(pred=pred.detach().clone(), targets=tg.clone(), anchors=det.anchors[0].clone(), hyp=dict(R.LOSS_HYP), gr=1.0,
+                          out=[x.detach().clone().reshape(-1) for x in ref], dpred=dref))
+    torch.save(cases, os.path.join(out, "loss.pt"))
+    print("[pin] wrote loss.pt")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-nms", action="store_true")
+    ap.add_argument("--only-loss", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
     ref_model, ref_vit, ref_common = import_reference()
+    if a.only_loss:
+        loss_goldens(GOLD)
+        return
+    loss_goldens(GOLD)
     nms_goldens(GOLD)
     if a.only_nms:
         return

@@ -501,6 +501,104 @@ def synthetic_predictions(B: int, N: int, nc: int, seed: int = 0, img: float = 1
 # ----------------------------------------------------------------------------
 # parameter construction with the reference's names/shapes
 # ----------------------------------------------------------------------------
+# ----------------------------------------------------------------------------
+# ComputeLoss (basics/utils/loss.py:90-224) with bbox_iou(CIoU) (basics/utils/general.py:347-389), functional
+# ----------------------------------------------------------------------------
+LOSS_HYP = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0)   # models/hyp.scratch.yaml
+
+
+def bbox_ciou(box1: Tensor, box2: Tensor, eps: float = 1e-7) -> Tensor:
+    """general.py:347-389 with x1y1x2y2=False, CIoU=True.  box1 (4, n) xywh, box2 (n, 4) xywh."""
+    box2 = box2.T
+    b1_x1, b1_x2 = box1[0] - box1[2] / 2, box1[0] + box1[2] / 2
+    b1_y1, b1_y2 = box1[1] - box1[3] / 2, box1[1] + box1[3] / 2
+    b2_x1, b2_x2 = box2[0] - box2[2] / 2, box2[0] + box2[2] / 2
+    b2_y1, b2_y2 = box2[1] - box2[3] / 2, box2[1] + box2[3] / 2
+    inter = (torch.min(b1_x2, b2_x2) - torch.max(b1_x1, b2_x1)).clamp(0) * \
+            (torch.min(b1_y2, b2_y2) - torch.max(b1_y1, b2_y1)).clamp(0)
+    w1, h1 = b1_x2 - b1_x1, b1_y2 - b1_y1 + eps
+    w2, h2 = b2_x2 - b2_x1, b2_y2 - b2_y1 + eps
+    union = w1 * h1 + w2 * h2 - inter + eps
+    iou = inter / union
+    cw = torch.max(b1_x2, b2_x2) - torch.min(b1_x1, b2_x1)
+    ch = torch.max(b1_y2, b2_y2) - torch.min(b1_y1, b2_y1)
+    c2 = cw ** 2 + ch ** 2 + eps
+    rho2 = ((b2_x1 + b2_x2 - b1_x1 - b1_x2) ** 2 + (b2_y1 + b2_y2 - b1_y1 - b1_y2) ** 2) / 4
+    v = (4 / math.pi ** 2) * torch.pow(torch.atan(w2 / h2) - torch.atan(w1 / h1), 2)
+    with torch.no_grad():
+        alpha = v / (v - iou + (1 + eps))
+    return iou - (rho2 / c2 + v * alpha)
+
+
+def build_targets(pred: Tensor, targets: Tensor, anchors: Tensor, anchor_t: float = 4.0):
+    """loss.py:165-224 for the single detection layer of model.yaml.  pred (B, na, ny, nx, no); targets (nt, 6) =
+    (image, class, x, y, w, h) normalised; anchors (na, 2) in grid units.  Returns tcls, tbox, (b, a, gj, gi), anch."""
+    na, nt = anchors.shape[0], targets.shape[0]
+    gain = torch.ones(7, dtype=targets.dtype)
+    ai = torch.arange(na, dtype=targets.dtype).view(na, 1).repeat(1, nt)
+    t7 = torch.cat((targets.repeat(na, 1, 1), ai[:, :, None]), 2)
+    g = 0.5
+    off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], dtype=targets.dtype) * g
+    gain[2:6] = torch.tensor(pred.shape, dtype=targets.dtype)[[3, 2, 3, 2]]
+    t = t7 * gain
+    if nt:
+        r = t[:, :, 4:6] / anchors[:, None]
+        j = torch.max(r, 1. / r).max(2)[0] < anchor_t
+        t = t[j]
+        gxy = t[:, 2:4]
+        gxi = gain[[2, 3]] - gxy
+        j, k = ((gxy % 1. < g) & (gxy > 1.)).T
+        l, m = ((gxi % 1. < g) & (gxi > 1.)).T
+        j = torch.stack((torch.ones_like(j), j, k, l, m))
+        t = t.repeat((5, 1, 1))[j]
+        offsets = (torch.zeros_like(gxy)[None] + off[:, None])[j]
+    else:
+        t = t7[0]
+        offsets = 0
+    b, c = t[:, :2].long().T
+    gxy, gwh = t[:, 2:4], t[:, 4:6]
+    gij = (gxy - offsets).long()
+    gi, gj = gij.T
+    a = t[:, 6].long()
+    idx = (b, a, gj.clamp(0, int(gain[3]) - 1), gi.clamp(0, int(gain[2]) - 1))
+    return c, torch.cat((gxy - gij, gwh), 1), idx, anchors[a]
+
+
+def compute_loss(pred: Tensor, targets: Tensor, anchors: Tensor, hyp: Optional[dict] = None, gr: float = 1.0, nc: int = 8):
+    """ComputeLoss.__call__ (loss.py:116-163), one layer (balance[0] = 4.0 for nl == 1, :110), BCE without focal term,
+    no label smoothing (smooth_BCE(0.0), :104).  Returns (loss * batch, lbox, lobj, lcls) like the reference."""
+    h = dict(LOSS_HYP if hyp is None else hyp)
+    lcls, lbox, lobj = pred.new_zeros(1), pred.new_zeros(1), pred.new_zeros(1)
+    tcls, tbox, (b, a, gj, gi), anch = build_targets(pred, targets, anchors, h["anchor_t"])
+    tobj = torch.zeros_like(pred[..., 0])
+    n = b.shape[0]
+    if n:
+        ps = pred[b, a, gj, gi]
+        pxy = ps[:, :2].sigmoid() * 2. - 0.5
+        pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * anch
+        iou = bbox_ciou(torch.cat((pxy, pwh), 1).T, tbox)
+        lbox = lbox + (1.0 - iou).mean()
+        tobj[b, a, gj, gi] = (1.0 - gr) + gr * iou.detach().clamp(0).type(tobj.dtype)     # duplicates: the last entry wins (CPU)
+        if nc > 1:
+            tc = torch.zeros_like(ps[:, 5:])
+            tc[range(n), tcls] = 1.0
+            lcls = lcls + F.binary_cross_entropy_with_logits(ps[:, 5:], tc, pos_weight=pred.new_tensor([h["cls_pw"]]))
+    lobj = lobj + F.binary_cross_entropy_with_logits(pred[..., 4], tobj, pos_weight=pred.new_tensor([h["obj_pw"]])) * 4.0
+    lbox, lobj, lcls = lbox * h["box"], lobj * h["obj"], lcls * h["cls"]
+    return (lbox + lobj + lcls) * pred.shape[0], lbox, lobj, lcls
+
+
+def synthetic_targets(B: int, per_image: int = 32, nc: int = 8, seed: int = 0) -> Tensor:
+    """per image `per_image` boxes, class ~U{0..nc-1}, centre ~U(0.05, 0.95), size ~U(0.01, 0.05)."""
+    g = torch.Generator().manual_seed(seed)
+    n = B * per_image
+    img = torch.arange(B).repeat_interleave(per_image).float()
+    cls = torch.randint(0, nc, (n,), generator=g).float()
+    xy = 0.05 + 0.9 * torch.rand(n, 2, generator=g)
+    wh = 0.01 + 0.04 * torch.rand(n, 2, generator=g)
+    return torch.cat((img[:, None], cls[:, None], xy, wh), 1)
+
+
 def state_dict_spec(img_size: int = 512, nc: int = 8) -> Dict[str, Tuple[int, ...]]:
     """name -> shape for every *parameter and float buffer* of Model(model.yaml).
     Integer / resolution-dependent buffers (relative_position_index, attn_mask,

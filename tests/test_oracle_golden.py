@@ -126,3 +126,16 @@ def test_nms_oracle_matches_reference_golden():
             assert torch.equal(i, ri)
             if o.numel():
                 assert float((o - ro).abs().max()) < 1e-3
+
+
+def test_compute_loss_matches_reference_goldens():
+    """oracle compute_loss / build_targets / CIoU against the reference's own ComputeLoss outputs (tests/golden/loss.pt,
+    written by oracle/gen_golden.py from basics/utils/loss.py): values and d(loss)/d(pred), incl. duplicate cells and no targets."""
+    cases = torch.load(os.path.join(GOLD, "loss.pt"))
+    for c in cases:
+        pred = c["pred"].clone().requires_grad_(True)
+        out = R.compute_loss(pred, c["targets"], c["anchors"], c["hyp"], c["gr"])
+        out[0].backward()
+        for a, b in zip(out, c["out"]):
+            assert float((a.detach().reshape(-1) - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+        assert float((pred.grad - c["dpred"]).abs().max()) <= 1e-7
