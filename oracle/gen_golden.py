@@ -245,6 +245,44 @@ def full_model_goldens(ref_model, out):
     print("[pin] wrote full_model_512.pt")
 
 
+def autocast_goldens(ref_model, out):
+    """What bf16 costs the REFERENCE ITSELF: the real Model @512^2 (procedural weights, the inputs of full_model_512.pt)
+    under torch.autocast(cpu, bfloat16) - the reference trains under amp.autocast (Train.py:405) - against its own f32 run:
+    logits and per-parameter gradient errors.  The bf16 throughput path of the build is gated at a multiple of these."""
+    Model = ref_model.Model
+    torch.manual_seed(0)
+    m = Model("/root/reference/models/model.yaml", input_mode="RGB+IR", ch_steam=3, ch=128, nc=8)
+    sd = R.procedural_state_dict(512, 8)
+    with torch.no_grad():
+        load_into(m, sd)
+    x_rgb, x_ir = R.synthetic_inputs(1, 512, seed=0)
+    m.train()
+    res = {}
+    for name, ctx in (("f32", None), ("bf16", torch.autocast("cpu", dtype=torch.bfloat16))):
+        for p in m.parameters():
+            p.grad = None
+        with torch.no_grad():
+            load_into(m, sd)                      # BN running stats back to the start
+        if ctx is None:
+            pred, _ = m(x_rgb, x_ir, "RGB+IR")
+        else:
+            with ctx:
+                pred, _ = m(x_rgb, x_ir, "RGB+IR")
+        pred[0].float().square().mean().backward()
+        res[name] = (pred[0].detach().float().clone(), {k: p.grad.detach().double().clone() for k, p in m.named_parameters()})
+        print(f"[pin] reference {name} forward+backward done")
+    (lf, gf), (lb, gb) = res["f32"], res["bf16"]
+    gmed = sorted(float(g.norm()) for g in gf.values())[len(gf) // 4]
+    grel = {k: float((gb[k] - gf[k]).norm() / (gf[k].norm() + 1e-2 * gmed + 1e-12)) for k in gf}
+    gold = dict(img_size=512, B=1, seed=0, logit_max=float(lf.abs().max()), logit_maxdiff=float((lb - lf).abs().max()),
+                logit_meandiff=float((lb - lf).abs().mean()), grad_rel=grel, grad_floor=1e-2 * gmed)
+    worst = sorted(grel.items(), key=lambda kv: -kv[1])[:5]
+    print(f"[pin] reference autocast(bf16) vs f32 @512^2: logits max|d| {gold['logit_maxdiff']:.3f} (|logit| max {gold['logit_max']:.2f}), "
+          f"mean|d| {gold['logit_meandiff']:.4f}; worst gradient relative errors {[(k, round(v, 3)) for k, v in worst]}")
+    torch.save(gold, os.path.join(out, "autocast_512.pt"))
+    print("[pin] wrote autocast_512.pt")
+
+
 def nms_goldens(out):
     """Run the reference's own non_max_suppression (general.py:425) - with torchvision.ops.nms, absent from
     this image, bound to the published greedy algorithm (R.greedy_nms) - and pin the oracle's restatement."""
@@ -318,12 +356,16 @@ def main():
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-nms", action="store_true")
     ap.add_argument("--only-loss", action="store_true")
+    ap.add_argument("--only-autocast", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
     ref_model, ref_vit, ref_common = import_reference()
     if a.only_loss:
         loss_goldens(GOLD)
+        return
+    if a.only_autocast:
+        autocast_goldens(ref_model, GOLD)
         return
     loss_goldens(GOLD)
     nms_goldens(GOLD)
@@ -332,6 +374,7 @@ def main():
     per_module_goldens(ref_vit, ref_common, GOLD)
     if not a.skip_full:
         full_model_goldens(ref_model, GOLD)
+        autocast_goldens(ref_model, GOLD)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,81 @@
+"""How far the bf16 throughput path is from the f32 parity path, gated by what bf16 costs the REFERENCE ITSELF:
+tests/golden/autocast_512.pt holds the real reference model @512^2 under torch.autocast(bfloat16) against its own f32 run
+(oracle/gen_golden.py: logits max|d| 0.29 on |logit| <= 4.3, per-parameter gradient errors up to 0.25).  The engine's bf16
+path (bf16 storage of every activation incl. the residual stream, f32 accumulate / LayerNorm / softmax) must stay within
+1.5x of those numbers on the same weights and inputs, at BASELINE's 1024^2 as well, and must pick (almost) the same NMS
+candidates as the f32 path."""
+import importlib
+import os
+
+import pytest
+import torch
+
+from test_model_gpu import build
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+PKG = "small-object-detection-transformers_amd"
+
+
+def _train_step(model, dt, x_rgb, x_ir):
+    model.compute_dtype = dt
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    pred, _ = model(x_rgb, x_ir, "RGB+IR")
+    pred[0].float().square().mean().backward()
+    torch.cuda.synchronize()
+    return pred[0].detach().float().clone(), {k: p.grad.detach().double().clone() for k, p in model.named_parameters()}
+
+
+def _compare(lf, gf, lb, gb, floor):
+    grel = {k: float((gb[k] - gf[k]).norm() / (gf[k].norm() + floor + 1e-12)) for k in gf}
+    return float((lb - lf).abs().max()), float((lb - lf).abs().mean()), grel
+
+
+@pytest.mark.parametrize("S", [512, 1024])
+def test_bf16_error_within_reference_autocast_error(dev, S):
+    from oracle import ref_torch as R
+    gold = torch.load(os.path.join(GOLD, "autocast_512.pt"))
+    model, _ = build(dev, S)
+    x_rgb, x_ir = R.synthetic_inputs(1, S, seed=0)
+    x_rgb, x_ir = x_rgb.to(dev), x_ir.to(dev)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    lf, gf = _train_step(model, torch.float32, x_rgb, x_ir)
+    model.load_state_dict(sd0)                                   # BN running statistics back to the start
+    lb, gb = _train_step(model, torch.bfloat16, x_rgb, x_ir)
+    gmed = sorted(float(g.norm()) for g in gf.values())[len(gf) // 4]
+    dmax, dmean, grel = _compare(lf, gf, lb, gb, 1e-2 * gmed)
+    worst = sorted(grel.items(), key=lambda kv: -kv[1])[:4]
+    print(f"\n[bf16 vs f32 @{S}^2] logits max|d| {dmax:.3f} mean|d| {dmean:.4f} (|logit| max {float(lf.abs().max()):.2f}); reference autocast: "
+          f"{gold['logit_maxdiff']:.3f} / {gold['logit_meandiff']:.4f}; worst gradient errors {[(k, round(v, 3)) for k, v in worst]}")
+    assert dmax <= 1.5 * gold["logit_maxdiff"] and dmean <= 1.5 * gold["logit_meandiff"]
+    zero_grad = "image_encoder.stage3.0.mlp.fc2.bias"            # mathematically zero gradient: pure rounding noise in any precision
+    bad = {k: (v, gold["grad_rel"][k]) for k, v in grel.items() if k != zero_grad and v > max(1.5 * gold["grad_rel"][k], 0.03)}
+    assert not bad, f"gradient errors above 1.5x the reference's own autocast error: {sorted(bad.items(), key=lambda kv: -kv[1][0])[:6]}"
+
+
+def test_bf16_and_f32_pick_the_same_nms_candidates(dev):
+    """non_max_suppression (general.py:425) on the eval output of the 512^2 golden input: bf16 against f32."""
+    from oracle import ref_torch as R
+    nms = importlib.import_module(PKG + ".nms")
+    model, _ = build(dev, 512)
+    x_rgb, x_ir = R.synthetic_inputs(1, 512, seed=0)
+    model.eval()
+    zs = {}
+    with torch.no_grad():
+        for dt in (torch.float32, torch.bfloat16):
+            model.compute_dtype = dt
+            zs[dt] = model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")[0]
+    zf, zb = zs[torch.float32], zs[torch.bfloat16]
+    score = (zf[..., 4:5] * zf[..., 5:]).max(-1).values
+    conf = float(score.flatten().kthvalue(int(0.98 * score.numel())).values)       # random-init scores are tiny: keep the top 2 %
+    (df,), (idf,) = nms.non_max_suppression(zf, conf, 0.45, multi_label=False, return_index=True)
+    (db,), (idb,) = nms.non_max_suppression(zb, conf, 0.45, multi_label=False, return_index=True)
+    sf, sb = set(idf.tolist()), set(idb.tolist())
+    common = len(sf & sb)
+    print(f"\n[NMS bf16 vs f32 @512^2] conf {conf:.2e}: kept {len(sf)} (f32) / {len(sb)} (bf16), {common} candidate ids in common "
+          f"({100.0 * common / max(len(sf), 1):.1f} %)")
+    # random-init scores sit within a few bf16 ulps of each other, so the cut and the suppression order differ near ties; a
+    # trained model's scores are not that degenerate.  The bulk must agree.
+    assert common >= 0.8 * len(sf)

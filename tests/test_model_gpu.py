@@ -31,7 +31,9 @@ def rel(a, b):
     return float((a - b).abs().max()), float(b.abs().max())
 
 
-@pytest.mark.parametrize("dtype,tol_logit,tol_grad", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 0.35, 0.25)])
+# bf16 bounds: 1.5x / 2x what this test measures (logits 0.197 on |logit| <= 3.25, worst gradient 0.085); the reference's own
+# bf16 autocast run differs from its f32 run by 0.29 / 0.25 (tests/golden/autocast_512.pt, tests/test_bf16_parity_gpu.py)
+@pytest.mark.parametrize("dtype,tol_logit,tol_grad", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 0.30, 0.17)])
 def test_train_step_vs_oracle(dev, dtype, tol_logit, tol_grad):
     from oracle import ref_torch as R
     S, B = 128, 2
