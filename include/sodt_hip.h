@@ -220,6 +220,14 @@ int sodt_copy_rows(const void* src, int lds_, void* dst, int ldd, int B, int Ho,
 int sodt_gather_sum_rows(const void* d, int ldd, void* dsrc, int lds_, int B, int Hs, int Ws, int shr, int C,
                          int accumulate, int dtype, sodt_stream_t st);
 
+/* nn.MaxPool2d(5, stride 1, padding 2), token-major, the unit of SPP (common.py:129-140: its 5 / 9 / 13 pools are this pool
+ * applied 1 / 2 / 3 times).  argmax (nullable in inference): one byte per (token, channel), window slot ky*5+kx of the
+ * first maximum in scan order (what PyTorch's backward routes to).  bwd: dx (+)= gather of dy through argmax. */
+int sodt_maxpool5_fwd(const void* x, int ldx, void* y, int ldy, unsigned char* argmax, int B, int H, int W, int C,
+                      int dtype, sodt_stream_t st);
+int sodt_maxpool5_bwd(const void* dy, int lddy, const unsigned char* argmax, void* dx, int lddx, int accumulate,
+                      int B, int H, int W, int C, int dtype, sodt_stream_t st);
+
 /* Detect: dpred f32 (B, na, HW, no) -> dz run dtype [B*HW][ldz] (cols >= na*no zeroed)  (model.py:55 backward) */
 int sodt_detect_unpermute(const float* dpred, void* dz, int ldz, int B, int HW, int na, int no,
                           int dtype, sodt_stream_t st);

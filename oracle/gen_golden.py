@@ -283,6 +283,37 @@ def autocast_goldens(ref_model, out):
     print("[pin] wrote autocast_512.pt")
 
 
+def spp_goldens(ref_common, out):
+    """common.SPP (c1 64 -> c2 96, train-mode BN) on a 2 x 64 x 12 x 10 map: output, input gradient, parameter gradients and
+    the oracle's restatement against them.  Values are rounded to a coarse grid so that window maxima TIE often: the
+    gradient routing of ties (first maximum in scan order) is part of what is pinned."""
+    torch.manual_seed(7)
+    m = ref_common.SPP(64, 96)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eps, mod.momentum = 1e-3, 0.03
+    sd = tiny_sd(m, 31)
+    with torch.no_grad():
+        load_into(m, sd)
+    x = (torch.randn(2, 64, 12, 10) * 2).round() / 2
+    x.requires_grad_(True)
+    m.train()
+    y = m(x)
+    gsel = R._hash01("spp", y.numel()).view(y.shape).float()
+    (y * gsel).sum().backward()
+    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    xo = x.detach().clone().requires_grad_(True)
+    yo = R.spp(osd, "", xo, True, {})
+    (yo * gsel).sum().backward()
+    print(f"[pin] SPP out {maxdiff(y, yo):.2e} dx {maxdiff(x.grad, xo.grad):.2e}")
+    assert maxdiff(y, yo) < 1e-5 and maxdiff(x.grad, xo.grad) < 1e-5
+    gold = dict(sd={k: v.clone() for k, v in sd.items()}, x=x.detach().clone(), y=y.detach().clone(), gsel=gsel, dx=x.grad.clone(),
+                grads={k: p.grad.clone() for k, p in m.named_parameters()},
+                stats_after={k: v.clone() for k, v in m.state_dict().items() if "running_" in k})
+    torch.save(gold, os.path.join(out, "spp.pt"))
+    print("[pin] wrote spp.pt")
+
+
 def nms_goldens(out):
     """Run the reference's own non_max_suppression (general.py:425) - with torchvision.ops.nms, absent from
     this image, bound to the published greedy algorithm (R.greedy_nms) - and pin the oracle's restatement."""
@@ -357,6 +388,7 @@ def main():
     ap.add_argument("--only-nms", action="store_true")
     ap.add_argument("--only-loss", action="store_true")
     ap.add_argument("--only-autocast", action="store_true")
+    ap.add_argument("--only-spp", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
@@ -367,11 +399,15 @@ def main():
     if a.only_autocast:
         autocast_goldens(ref_model, GOLD)
         return
+    if a.only_spp:
+        spp_goldens(ref_common, GOLD)
+        return
     loss_goldens(GOLD)
     nms_goldens(GOLD)
     if a.only_nms:
         return
     per_module_goldens(ref_vit, ref_common, GOLD)
+    spp_goldens(ref_common, GOLD)
     if not a.skip_full:
         full_model_goldens(ref_model, GOLD)
         autocast_goldens(ref_model, GOLD)

@@ -324,6 +324,13 @@ def c3(sd: SD, pfx: str, x: Tensor, training: bool, new_stats: Optional[dict]) -
     return conv_bn_silu(sd, pfx + "cv3.", torch.cat((a, b), 1), training, new_stats)
 
 
+def spp(sd: SD, pfx: str, x: Tensor, training: bool, new_stats: Optional[dict]) -> Tensor:
+    """SPP.forward (common.py:129-140): cv1 -> MaxPool2d(5 | 9 | 13, stride 1, same padding) -> cat -> cv2."""
+    a = conv_bn_silu(sd, pfx + "cv1.", x, training, new_stats)
+    pools = [F.max_pool2d(a, k, 1, k // 2) for k in (5, 9, 13)]
+    return conv_bn_silu(sd, pfx + "cv2.", torch.cat([a] + pools, 1), training, new_stats)
+
+
 def detect_raw(sd: SD, pfx: str, x: Tensor, na: int = 3) -> Tensor:
     """Detect.forward train branch (model.py:48-55)."""
     w = sd[pfx + "m.0.weight"]

@@ -97,6 +97,8 @@ SIGNATURES = {
     "sodt_batch_sum": [_P, _P, _I, _L, _I, _P],
     "sodt_memset_zero": [_P, _L, _P],
     "sodt_gemm_set_variant": [_I],
+    "sodt_maxpool5_fwd": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "sodt_maxpool5_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "sodt_yolo_loss_workspace_bytes": [_L, _I, _I, C.POINTER(C.c_size_t)],
     "sodt_yolo_loss": [_P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _P, C.c_size_t, _P, _P, _P],
     "sodt_sgd_ema_step": [_P, _P, _P, _P, _P, _I, _P, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -200,6 +200,17 @@ class C3(_Container):           # common.py:114-127
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
 
+class SPP(_Container):          # common.py:129-140; operator: spp.SPPOp (cascade of sodt_maxpool5 + K-segment concat)
+    def __init__(self, c1, c2, k=(5, 9, 13)):
+        super().__init__()
+        if tuple(k) != (5, 9, 13):
+            raise NotImplementedError("SPP pools (5, 9, 13): the cascade of three 5x5 pools (csrc/pool.hip)")
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
+
+
 class Concat(_Container):       # common.py:275-282
     def __init__(self, dimension=1):
         super().__init__()
@@ -241,7 +252,7 @@ def check_anchor_order(m):      # basics/utils/autoanchor.py:13-21
 
 
 _MODULES = {"Conv": Conv, "C3": C3, "Concat": Concat, "Detect": Detect, "nn.Upsample": Upsample,
-            "ImageEncoderViT": ImageEncoderViT, "Bottleneck": Bottleneck}
+            "ImageEncoderViT": ImageEncoderViT, "Bottleneck": Bottleneck, "SPP": SPP}
 
 
 def parse_model(d: dict, string: str, ch: List[int]):
@@ -264,7 +275,7 @@ def parse_model(d: dict, string: str, ch: List[int]):
             if isinstance(a, str):
                 args[j] = {"nc": nc, "anchors": anchors, "None": None, "False": False, "True": True}.get(a, a)
         n = max(round(n * gd), 1) if n > 1 else n
-        if cls in (Conv, C3, Bottleneck):
+        if cls in (Conv, C3, Bottleneck, SPP):      # model.py:378-381
             c1, c2 = ch[f], args[0]
             c2 = make_divisible(c2 * gw, 8) if c2 != no else c2
             args = [c1, c2, *args[1:]]

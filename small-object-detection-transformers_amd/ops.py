@@ -393,6 +393,19 @@ def sgd_ema_step(p, g, mom, ema, p_cast, group_of_chunk, lr, momentum, weight_de
             arr(lr), arr(momentum), arr(weight_decay), int(bool(nesterov)), C.c_float(grad_scale), C.c_float(ema_decay))
 
 
+def maxpool5_fwd(x, y, argmax, B, H, W, Cc, ldx=None, ldy=None, x_off=0, y_off=0):
+    """y = MaxPool2d(5, 1, 2)(x), token-major; x / y may be channel slices of wider tensors (ld*, *_off in elements)."""
+    es = x.element_size()
+    _launch("sodt_maxpool5_fwd", x.data_ptr() + x_off * es, x.shape[-1] if ldx is None else ldx, y.data_ptr() + y_off * es,
+            y.shape[-1] if ldy is None else ldy, _p(argmax), B, H, W, Cc, dt_code(x))
+
+
+def maxpool5_bwd(dy, argmax, dx, B, H, W, Cc, lddy=None, lddx=None, dy_off=0, dx_off=0, accumulate=False):
+    es = dy.element_size()
+    _launch("sodt_maxpool5_bwd", dy.data_ptr() + dy_off * es, dy.shape[-1] if lddy is None else lddy, _p(argmax),
+            dx.data_ptr() + dx_off * es, dx.shape[-1] if lddx is None else lddx, int(bool(accumulate)), B, H, W, Cc, dt_code(dy))
+
+
 def gemm_set_variant(v) -> None:
     """0/False: automatic; 1/True: force the K-loop tile kernel; 2: force the A-stationary kernel (tests)."""
     _lib.sodt_gemm_set_variant(int(v))

@@ -43,3 +43,28 @@ def test_batch_of_8_is_8_independent_images_bf16(dev):
             assert e <= 2e-2 * max(1.0, s), f"image {i}: raw head output differs by {e:.3e} (scale {s:.2f})"
             e, s = rel(z1[0], z8[i])
             assert e <= 2e-2 * max(1.0, s), f"image {i}: decoded rows differ by {e:.3e}"
+
+
+def test_2048_resolution_eval_and_train_step(dev):
+    """BASELINE.json config 5's resolution (2048 x 2048: 262,144 stage-1 tokens per image, 4,096 windows) runs through the
+    engine: a batch of 2 reproduces its single-image results in eval mode (the property used at 1024^2), the fused W-MSA
+    kernel's 2^31 byte-offset guard holds, and one bf16 training step gives finite gradients for every parameter."""
+    from oracle import ref_torch as R
+    model, _ = build(dev, 2048)
+    model.compute_dtype = torch.bfloat16
+    model.eval()
+    x_rgb, x_ir = R.synthetic_inputs(2, 2048, seed=6)
+    x_rgb, x_ir = x_rgb.to(dev), x_ir.to(dev)
+    with torch.no_grad():
+        z2, p2, _ = model(x_rgb, x_ir, "RGB+IR")
+        z2, raw2 = z2.clone(), p2[0].clone()
+        assert z2.shape == (2, 3 * 512 * 512, 13)
+        z1, p1, _ = model(x_rgb[1:2], x_ir[1:2], "RGB+IR")
+        e, s = rel(p1[0][0], raw2[1])
+        assert e <= 2e-2 * max(1.0, s), f"2048^2: raw head output of image 1 differs by {e:.3e} (scale {s:.2f})"
+    model.train()
+    pred, _ = model(x_rgb[:1], x_ir[:1], "RGB+IR")
+    pred[0].float().square().mean().backward()
+    torch.cuda.synchronize()
+    bad = [n for n, p in model.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
+    assert not bad, bad[:5]

@@ -139,3 +139,16 @@ def test_compute_loss_matches_reference_goldens():
         for a, b in zip(out, c["out"]):
             assert float((a.detach().reshape(-1) - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
         assert float((pred.grad - c["dpred"]).abs().max()) <= 1e-7
+
+
+def test_spp_matches_reference_golden():
+    """oracle spp() against the reference's common.SPP (tests/golden/spp.pt): output and input gradient."""
+    g = torch.load(os.path.join(GOLD, "spp.pt"))
+    sd = {k: v.clone() for k, v in g["sd"].items()}
+    x = g["x"].clone().requires_grad_(True)
+    ns = {}
+    y = R.spp(sd, "", x, True, ns)
+    (y * g["gsel"]).sum().backward()
+    assert float((y - g["y"]).abs().max()) < 1e-5 and float((x.grad - g["dx"]).abs().max()) < 1e-5
+    for k, v in g["stats_after"].items():
+        assert float((ns[k] - v).abs().max()) < 1e-5
