@@ -77,7 +77,7 @@ SIGNATURES = {
     "sodt_wmsa_block_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sodt_window_attn_bwd_wm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sodt_frontend_fwd": [_P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "sodt_frontend_bwd": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sodt_frontend_bwd": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _I, _P],
     "sodt_patch_embed4_fwd": [_P, _P, _L, _P, _P, _P, _I, _I, _P],
     "sodt_patch_embed4_bwd": [_P, _P, _L, _P, _P, _P, _I, _I, _P],
     "sodt_cross_attn_ln_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -125,6 +125,8 @@ def load():
         fn.restype = C.c_int
     lib.sodt_wmsa_pack_bytes.argtypes = [_I, _I, _I, _I]
     lib.sodt_wmsa_pack_bytes.restype = C.c_long
+    lib.sodt_frontend_bwd_workspace_bytes.argtypes = [_I, _I]
+    lib.sodt_frontend_bwd_workspace_bytes.restype = C.c_long
     lib.sodt_version.restype = C.c_char_p
     lib.sodt_version.argtypes = []
     _lib = lib
@@ -132,4 +134,4 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGNATURES.keys()) + ["sodt_version", "sodt_wmsa_pack_bytes"]
+    return list(SIGNATURES.keys()) + ["sodt_version", "sodt_wmsa_pack_bytes", "sodt_frontend_bwd_workspace_bytes"]

@@ -741,8 +741,9 @@ class Engine:
         cb = self.model.image_encoder.chan_block
         ca_ws, ca_shift = int(cb.window_size), int(cb.shift_size)
         if ca_ws == 1:
+            ws = plan.buf("fe.ws", (ops.frontend_bwd_workspace_bytes(B, S) // 4,), torch.float32)
             ops.frontend_bwd(x_rgb, x_ir, x_ir.shape[1] * S * S, fe["w"], fe["b"], fe["g"], fe["be"], plan.bufs["g.dx0"],
-                             self.g_fe_w, self.g_fe_b, self.g_fe_g, self.g_fe_be, B, S, 1)
+                             self.g_fe_w, self.g_fe_b, self.g_fe_g, self.g_fe_be, B, S, 1, ws)
         else:
             de = plan.buf("fe.de", (B * t * t, 192), torch.float32)
             ops.zero_(de)

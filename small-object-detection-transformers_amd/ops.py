@@ -281,9 +281,15 @@ def frontend_fwd(rgb, ir_plane, ir_bstride, w, b, gamma, beta, out, B, S, ca_ws=
             B, S, ca_ws, dt_code(out))
 
 
-def frontend_bwd(rgb, ir_plane, ir_bstride, w, b, gamma, beta, dout, dw, db, dgamma, dbeta, B, S, ca_ws=1):
+def frontend_bwd_workspace_bytes(B: int, S: int) -> int:
+    return int(_lib.sodt_frontend_bwd_workspace_bytes(B, S))
+
+
+def frontend_bwd(rgb, ir_plane, ir_bstride, w, b, gamma, beta, dout, dw, db, dgamma, dbeta, B, S, ca_ws=1, ws=None):
+    """``ws``: f32 scratch of ``frontend_bwd_workspace_bytes`` (two-stage reduction); None = direct atomics."""
     _launch("sodt_frontend_bwd", _p(rgb), _p(ir_plane), ir_bstride, _p(w), _p(b), _p(gamma), _p(beta), _p(dout),
-            _p(dw), _p(db), _p(dgamma), _p(dbeta), B, S, ca_ws, dt_code(dout))
+            _p(dw), _p(db), _p(dgamma), _p(dbeta), B, S, ca_ws, _p(ws), 0 if ws is None else ws.numel() * ws.element_size(),
+            dt_code(dout))
 
 
 def patch_embed4_fwd(rgb, ir_plane, ir_bstride, w, b, e, B, S):

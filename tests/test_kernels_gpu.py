@@ -446,9 +446,9 @@ def test_window_attention(ops, dev, dt, Cc, H, W, ws, shift):
 
 # ------------------------------------------------------------------ front end
 @pytest.mark.parametrize("dt", DTYPES)
-def test_frontend(ops, dev, dt):
+@pytest.mark.parametrize("B,S", [(2, 96), (3, 352)])
+def test_frontend(ops, dev, dt, B, S):
     from oracle import ref_torch as R
-    B, S = 2, 96
     sd = {k: v.to(dev) for k, v in R.procedural_state_dict(S, 8).items() if "channel_embed" in k or "chan_block" in k}
     x_rgb, x_ir = R.synthetic_inputs(B, S, seed=3)
     x_rgb, x_ir = x_rgb.to(dev), x_ir.to(dev)
@@ -467,13 +467,15 @@ def test_frontend(ops, dev, dt):
     close(out, ref, dt, what="frontend fwd")
     dout = rnd((B * t * t, 192), dev, dt, 5)
     ref.backward(dout.float().double())
-    dw, db, dg, dbe = torch.zeros_like(w), torch.zeros_like(b), torch.zeros_like(g), torch.zeros_like(be)
-    ops.frontend_bwd(x_rgb, ir_plane, 3 * S * S, w, b, g, be, dout, dw, db, dg, dbe, B, S)
-    for ci, c in enumerate("rgbi"):
-        close(dw[ci], sdd[f"image_encoder.channel_embed_{c}.proj.weight"].grad.view(48, 16), dt, what=f"dw {c}")
-        close(db[ci], sdd[f"image_encoder.channel_embed_{c}.proj.bias"].grad, dt, what=f"db {c}")
-        close(dg[ci], sdd[f"image_encoder.chan_block.norm{ci + 1}.weight"].grad, dt, what=f"dgamma {ci}")
-        close(dbe[ci], sdd[f"image_encoder.chan_block.norm{ci + 1}.bias"].grad, dt, what=f"dbeta {ci}")
+    # direct atomics (no workspace) and the two-stage reduction through a workspace (filled with junk: it need not be zeroed)
+    for ws in (None, torch.full((ops.frontend_bwd_workspace_bytes(B, S) // 4,), 7.0, device=dev)):
+        dw, db, dg, dbe = torch.zeros_like(w), torch.zeros_like(b), torch.zeros_like(g), torch.zeros_like(be)
+        ops.frontend_bwd(x_rgb, ir_plane, 3 * S * S, w, b, g, be, dout, dw, db, dg, dbe, B, S, 1, ws)
+        for ci, c in enumerate("rgbi"):
+            close(dw[ci], sdd[f"image_encoder.channel_embed_{c}.proj.weight"].grad.view(48, 16), dt, what=f"dw {c}")
+            close(db[ci], sdd[f"image_encoder.channel_embed_{c}.proj.bias"].grad, dt, what=f"db {c}")
+            close(dg[ci], sdd[f"image_encoder.chan_block.norm{ci + 1}.weight"].grad, dt, what=f"dgamma {ci}")
+            close(dbe[ci], sdd[f"image_encoder.chan_block.norm{ci + 1}.bias"].grad, dt, what=f"dbeta {ci}")
 
 
 @pytest.mark.parametrize("dt", DTYPES)
