@@ -1612,6 +1612,387 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mt_kernel(const T* __restric
 #undef MT_ISSUE
 #undef MT_STORE_ONE
 
+// ---------------------------------------------------------------------------------
+// backward, unshifted windows of more than 64 tokens (stage 3: 32x32 windows, head_dim 64), two passes without global
+// dQ atomics.  attn_bwd_mt_kernel walks the query tiles per key tile and adds every dQ strip into an f32 accumulator
+// with global atomics: 64 atomic instructions per (query tile, key tile) pair, 4 x 10^8 atomic lane operations at the
+// bench shape - they, not the MFMAs, were its 3 ms.  Here
+//   attn_bwd_dkv_kernel  one workgroup = four waves = four 32-key tiles of ONE (window, head); the 64-query tiles
+//                        (Q, dO, lse, delta) are staged once per workgroup (double buffered, next tile prefetched in
+//                        registers) and shared; K / V fragments and dK / dV stay in registers.  S = Q K^T and
+//                        dP = dO V^T come out with queries on the accumulator rows, so P and dS leave the accumulators
+//                        as the A operands of dV += P^T dO and dK += dS^T Q (as in attn_bwd_fast2_kernel).
+//   attn_bwd_dq_kernel   one workgroup = four waves = four 32-query tiles of ONE (window, head), the 64-key K / V tiles
+//                        staged once per workgroup and shared (as attn_fwd_mt_kernel); Q / dO fragments and dQ in
+//                        registers (32 queries per wave keep the kernel under 256 registers with the K / V prefetch
+//                        live: a spilled prefetch waits for its own load at the top of every iteration).  S^T = K Q^T, dP^T = V dO^T:
+//                        keys on the accumulator rows, so dS leaves them as the A operand of dQ += dS K.  dQ is written
+//                        once, in the run dtype (no f32 accumulator, no finish kernel).  The bias gradient of the head
+//                        is summed in one (2ws-1)^2 LDS table per workgroup.
+// P is recomputed in both passes (7 instead of 5 tile products); both are VALU/MFMA balanced and free of atomics in the
+// pair loop.  The relative-position bias of a 16 x 16 tile is four consecutive table entries per lane: the (few) table
+// rows a pair touches are staged per wave in four copies shifted by one entry, so every lane reads its four values with
+// one aligned 16-byte LDS load (no per-element gather, no index arithmetic per element).
+// ---------------------------------------------------------------------------------
+// value of the lane n positions up / down the 16-lane row, 0 beyond the row's ends (DPP row_shl / row_shr, bound_ctrl)
+template <int N> __device__ __forceinline__ float dpp_row_shl(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+template <int N> __device__ __forceinline__ float dpp_row_shr(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, true));
+}
+
+constexpr int BWD2_BT = 1024;   // floats of staged bias per wave: (rows) x 4 copies x 2 ws
+
+// window-local token n of the unshifted window (b, wy, wx) -> token row
+__device__ __forceinline__ int win_row0(const AttnGeo& g, int b, int wy, int wx, int n) {
+  const int iy = n / g.ws, ix = n - iy * g.ws;
+  return (b * g.H + wy * g.ws + iy) * g.W + wx * g.ws + ix;
+}
+
+// stage rows dy = dymin .. dymin + nr - 1 of the head's table (x log2 e), 4 shifted copies of 2 ws floats each:
+// copy c, slot m holds entry j = m + c of the row, where j = dx + ws - 1 (REV: j = -dx + ws - 1)
+template <bool REV>
+__device__ __forceinline__ void stage_bias_rows(float* dst, const float* bt, int ws, int dymin, int nr, int lane) {
+  const int L2 = 2 * ws - 1, RL = 2 * ws;
+  for (int i = lane; i < nr * 4 * RL; i += 64) {
+    const int a = i / (4 * RL), rem = i - a * 4 * RL;
+    const int c = rem / RL, m = rem - c * RL;
+    const int j = m + c, gy = dymin + a + ws - 1;
+    dst[i] = (gy >= 0 && gy < L2 && j < L2) ? bt[gy * L2 + (REV ? L2 - 1 - j : j)] * SODT_LOG2E : 0.f;
+  }
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkv_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ bias_t, const T* __restrict__ d_out, const float* __restrict__ lse,
+    const float* __restrict__ delta, T* __restrict__ dqkv, const AttnGeo g) {
+  using L = Lay<T, HD>;
+  constexpr int E = L::E, KPL = L::KPL, MK = TT<T>::MMA_K, SPK = MK / 16, KBQ = L::KBQ, DB = HD / 16;
+  constexpr int NPF = 64 * L::DCH / 256;           // 16-byte chunks per thread, tensor and query tile
+  static_assert(HD % MK == 0 && NPF >= 1 && NPF <= 4, "head_dim");
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[2][L::QTILE], sDO[2][L::QTILE];
+  __shared__ __attribute__((aligned(16))) float sLse[2][64], sDel[2][64];
+  __shared__ __attribute__((aligned(16))) float sBias[4][BWD2_BT];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nkg = g.N / 128;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int kvg = bid % nkg; bid /= nkg;
+  const int head = bid % g.heads; bid /= g.heads;
+  const int wx = bid % g.nwx; bid /= g.nwx;
+  const int wy = bid % g.nwy; const int b = bid / g.nwy;
+  const int C3 = 3 * g.C, L2 = 2 * g.ws - 1, RL = 2 * g.ws;
+  const int Rq = g.ws >= 64 ? 1 : 64 / g.ws, Rk = g.ws >= 32 ? 1 : 32 / g.ws;
+  const float scale = rsqrtf((float)HD), scale2 = scale * SODT_LOG2E;
+  const float* bt = bias_t + (long)head * L2 * L2;
+  const int kb0 = (kvg * 4 + w) * 32;              // this wave's 32 keys (window-local)
+  float* myB = sBias[w];
+
+  // K / V fragments of the wave's keys: B operands of S = Q K^T and dP = dO V^T (lane: key fr of strip ns, 16 bytes of d)
+  uint4 kf[2][KBQ], vf[2][KBQ];
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns) {
+    const T* src = qkv + (long)win_row0(g, b, wy, wx, kb0 + ns * 16 + fr) * C3 + head * HD + KPL * fg;
+#pragma unroll
+    for (int kb = 0; kb < KBQ; ++kb) {
+      kf[ns][kb] = *(const uint4*)(src + g.C + kb * MK);
+      vf[ns][kb] = *(const uint4*)(src + 2 * g.C + kb * MK);
+    }
+  }
+  f32x4 dk[2][DB], dv[2][DB];
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) { dk[ns][d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ns][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // next query tile in registers (named scalars: hipcc leaves uint4 arrays used like this in scratch)
+  uint4 pq0, pq1, pq2, pq3, pd0, pd1, pd2, pd3;
+  float pls = 0.f;
+#define KV_ISSUE_ONE(i, QT_)                                                            \
+  if constexpr (NPF > i) {                                                              \
+    const int idx = tid + i * 256;                                                      \
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;                                  \
+    const long row = win_row0(g, b, wy, wx, (QT_) * 64 + r);                            \
+    pq##i = *(const uint4*)(qkv + row * C3 + head * HD + dc * KPL);                     \
+    pd##i = *(const uint4*)(d_out + row * g.C + head * HD + dc * KPL);                  \
+  }
+#define KV_ISSUE(QT_) {                                                                 \
+    KV_ISSUE_ONE(0, QT_) KV_ISSUE_ONE(1, QT_) KV_ISSUE_ONE(2, QT_) KV_ISSUE_ONE(3, QT_) \
+    if (tid < 128) {                                                                    \
+      const long row = win_row0(g, b, wy, wx, (QT_) * 64 + (tid & 63));                 \
+      pls = tid < 64 ? lse[row * g.heads + head] * SODT_LOG2E : delta[row * g.heads + head]; \
+    }                                                                                   \
+  }
+#define KV_STORE_ONE(i, BUF_)                                                           \
+  if constexpr (NPF > i) {                                                              \
+    const int idx = tid + i * 256;                                                      \
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;                                  \
+    *(uint4*)(sQ[BUF_] + r * L::QROW + dc * 16) = pq##i;                                \
+    *(uint4*)(sDO[BUF_] + r * L::QROW + dc * 16) = pd##i;                               \
+  }
+#define KV_STORE(BUF_) {                                                                \
+    KV_STORE_ONE(0, BUF_) KV_STORE_ONE(1, BUF_) KV_STORE_ONE(2, BUF_) KV_STORE_ONE(3, BUF_) \
+    if (tid < 64) sLse[BUF_][tid] = pls; else if (tid < 128) sDel[BUF_][tid - 64] = pls; \
+  }
+  KV_ISSUE(0)
+  KV_STORE(0)
+
+  const int ky0 = kb0 / g.ws;
+  for (int qt = 0; qt < g.nqt; ++qt) {
+    const int cur = qt & 1;
+    __syncthreads();            // tile qt is staged; every wave is done with the other buffer
+    { const int nq_ = qt + 1 < g.nqt ? qt + 1 : qt; KV_ISSUE(nq_) }
+    const int qy0 = (qt * 64) / g.ws;
+    const int dymin = qy0 - ky0 - (Rk - 1);
+    stage_bias_rows<false>(myB, bt, g.ws, dymin, Rq + Rk - 1, lane);
+    wave_sync();
+    const unsigned char* cQ = sQ[cur]; const unsigned char* cDO = sDO[cur];
+
+#pragma unroll
+    for (int kbq = 0; kbq < 4 / SPK; ++kbq) {
+      uint4 Ap[2], Ads[2];
+#pragma unroll
+      for (int hh = 0; hh < SPK; ++hh) {
+        const int ms = kbq * SPK + hh;
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < KBQ; ++kb) {
+          const uint4 fq = frag<T>(cQ, L::QROW, ms * 16, kb, HD, lane);
+          const uint4 fo = frag<T>(cDO, L::QROW, ms * 16, kb, HD, lane);
+#pragma unroll
+          for (int ns = 0; ns < 2; ++ns) {
+            if (kb == 0) { s[ns] = mma16z<T>(fq, kf[ns][0]); dp[ns] = mma16z<T>(fo, vf[ns][0]); }
+            else { mma16<T>(s[ns], fq, kf[ns][kb]); mma16<T>(dp[ns], fo, vf[ns][kb]); }
+          }
+        }
+        // rows 4 fg + r of the strip: queries; column fr: key
+        const float4 lq = *(const float4*)&sLse[cur][ms * 16 + 4 * fg];
+        const float4 dl = *(const float4*)&sDel[cur][ms * 16 + 4 * fg];
+        const float lqa[4] = {lq.x, lq.y, lq.z, lq.w}, dla[4] = {dl.x, dl.y, dl.z, dl.w};
+        const int qn0 = qt * 64 + ms * 16;
+        const int qy = qn0 / g.ws, qx0 = qn0 - qy * g.ws;
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns) {
+          const int kn0 = kb0 + ns * 16;
+          const int ky = kn0 / g.ws, kx0 = kn0 - ky * g.ws;
+          const int j0 = qx0 + 4 * fg - kx0 - fr + g.ws - 1;       // entries j0 .. j0 + 3 <-> queries 4 fg .. 4 fg + 3
+          const float4 b4 = *(const float4*)&myB[((qy - ky - dymin) * 4 + (j0 & 3)) * RL + (j0 & ~3)];
+          const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fast_exp2(fmaf(s[ns][r], scale2, ba[r]) - lqa[r]);
+            s[ns][r] = p;
+            dp[ns][r] = p * (dp[ns][r] - dla[r]);
+          }
+          if constexpr (std::is_same<T, bf16>::value) {
+            const uint32_t p01 = pack2bf(s[ns][0], s[ns][1]), p23 = pack2bf(s[ns][2], s[ns][3]);
+            const uint32_t d01 = pack2bf(dp[ns][0], dp[ns][1]), d23 = pack2bf(dp[ns][2], dp[ns][3]);
+            if (hh == 0) { Ap[ns].x = p01; Ap[ns].y = p23; Ads[ns].x = d01; Ads[ns].y = d23; }
+            else { Ap[ns].z = p01; Ap[ns].w = p23; Ads[ns].z = d01; Ads[ns].w = d23; }
+          } else {
+            Ap[ns] = make_uint4(__float_as_uint(s[ns][0]), __float_as_uint(s[ns][1]), __float_as_uint(s[ns][2]), __float_as_uint(s[ns][3]));
+            Ads[ns] = make_uint4(__float_as_uint(dp[ns][0]), __float_as_uint(dp[ns][1]), __float_as_uint(dp[ns][2]), __float_as_uint(dp[ns][3]));
+          }
+        }
+      }
+      // dV += P^T dO, dK += dS^T Q over the queries of this strip (pair)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const uint4 fdo = fragTp<T>(cDO, L::QROW, kbq, d * 16, lane);
+        const uint4 fqq = fragTp<T>(cQ, L::QROW, kbq, d * 16, lane);
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns) {
+          mma16<T>(dv[ns][d], Ap[ns], fdo);
+          mma16<T>(dk[ns][d], Ads[ns], fqq);
+        }
+      }
+    }
+    KV_STORE(cur ^ 1)
+  }
+#undef KV_ISSUE_ONE
+#undef KV_ISSUE
+#undef KV_STORE_ONE
+#undef KV_STORE
+  // ---- dK (rows 0..31) and dV (rows 32..63) of the wave's keys staged through one of the four tiles, coalesced store
+  __syncthreads();
+  unsigned char* st = w < 2 ? sQ[w] : sDO[w - 2];
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        st_elem<T>(st + (ns * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dk[ns][d][r] * scale);
+        st_elem<T>(st + (32 + ns * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dv[ns][d][r]);
+      }
+  wave_sync();
+  for (int idx = lane; idx < 64 * L::DCH; idx += 64) {
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;
+    T* dst = dqkv + (long)win_row0(g, b, wy, wx, kb0 + (r & 31)) * C3 + (r < 32 ? g.C : 2 * g.C) + head * HD + dc * KPL;
+    *(uint4*)dst = *(const uint4*)(st + r * L::QROW + dc * 16);
+  }
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ bias_t, const T* __restrict__ d_out, const float* __restrict__ lse,
+    const float* __restrict__ delta, T* __restrict__ dqkv, float* __restrict__ dbias_t, const AttnGeo g) {
+  using L = Lay<T, HD>;
+  constexpr int E = L::E, KPL = L::KPL, MK = TT<T>::MMA_K, SPK = MK / 16, KBQ = L::KBQ, DB = HD / 16;
+  constexpr int NPF = 64 * L::DCH / 256;
+  static_assert(HD % MK == 0 && NPF >= 1 && NPF <= 4, "head_dim");
+  __shared__ __attribute__((aligned(16))) unsigned char sK[2][L::QTILE], sV[2][L::QTILE];
+  __shared__ __attribute__((aligned(16))) float sBias[4][BWD2_BT];
+  __shared__ float sDB[63 * 63 + 3];               // bias gradient of the head (ws <= 32)
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nqg = g.N / 128;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qg = bid % nqg; bid /= nqg;
+  const int head = bid % g.heads; bid /= g.heads;
+  const int wx = bid % g.nwx; bid /= g.nwx;
+  const int wy = bid % g.nwy; const int b = bid / g.nwy;
+  const int q0 = (qg * 4 + w) * 32;                // this wave's 32 queries (window-local)
+  const int C3 = 3 * g.C, L2 = 2 * g.ws - 1, RL = 2 * g.ws;
+  const int Rq = g.ws >= 32 ? 1 : 32 / g.ws, Rk = g.ws >= 64 ? 1 : 64 / g.ws;
+  const float scale = rsqrtf((float)HD), scale2 = scale * SODT_LOG2E;
+  const float* bt = bias_t + (long)head * L2 * L2;
+  float* myB = sBias[w];
+  for (int i = tid; i < L2 * L2; i += 256) sDB[i] = 0.f;
+
+  // Q / dO fragments of the wave's queries: B operands of S^T = K Q^T and dP^T = V dO^T (lane: query fr of strip ms)
+  uint4 fq[2][KBQ], fo[2][KBQ];
+  float lq[2], dl[2];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms) {
+    const long row = win_row0(g, b, wy, wx, q0 + ms * 16 + fr);
+#pragma unroll
+    for (int kb = 0; kb < KBQ; ++kb) {
+      fq[ms][kb] = *(const uint4*)(qkv + row * C3 + head * HD + kb * MK + KPL * fg);
+      fo[ms][kb] = *(const uint4*)(d_out + row * g.C + head * HD + kb * MK + KPL * fg);
+    }
+    lq[ms] = lse[row * g.heads + head] * SODT_LOG2E;
+    dl[ms] = delta[row * g.heads + head];
+  }
+  f32x4 dq[2][DB];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) dq[ms][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 pk0, pk1, pk2, pk3, pv0, pv1, pv2, pv3;
+#define DQ_ISSUE_ONE(i, KT_)                                                            \
+  if constexpr (NPF > i) {                                                              \
+    const int idx = tid + i * 256;                                                      \
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;                                  \
+    const T* src = qkv + (long)win_row0(g, b, wy, wx, (KT_) * 64 + r) * C3 + head * HD + dc * KPL; \
+    pk##i = *(const uint4*)(src + g.C); pv##i = *(const uint4*)(src + 2 * g.C);         \
+  }
+#define DQ_ISSUE(KT_) { DQ_ISSUE_ONE(0, KT_) DQ_ISSUE_ONE(1, KT_) DQ_ISSUE_ONE(2, KT_) DQ_ISSUE_ONE(3, KT_) }
+#define DQ_STORE_ONE(i, BUF_)                                                           \
+  if constexpr (NPF > i) {                                                              \
+    const int idx = tid + i * 256;                                                      \
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;                                  \
+    *(uint4*)(sK[BUF_] + r * L::QROW + dc * 16) = pk##i; *(uint4*)(sV[BUF_] + r * L::QROW + dc * 16) = pv##i; \
+  }
+#define DQ_STORE(BUF_) { DQ_STORE_ONE(0, BUF_) DQ_STORE_ONE(1, BUF_) DQ_STORE_ONE(2, BUF_) DQ_STORE_ONE(3, BUF_) }
+  DQ_ISSUE(0)
+  DQ_STORE(0)
+
+  const int qy0 = q0 / g.ws;
+  for (int kt = 0; kt < g.nqt; ++kt) {
+    const int cur = kt & 1;
+    __syncthreads();
+    { const int nk_ = kt + 1 < g.nqt ? kt + 1 : kt; DQ_ISSUE(nk_) }
+    const int ky0 = (kt * 64) / g.ws;
+    const int dymin = qy0 - ky0 - (Rk - 1);
+    stage_bias_rows<true>(myB, bt, g.ws, dymin, Rq + Rk - 1, lane);
+    wave_sync();
+    const unsigned char* cK = sK[cur]; const unsigned char* cV = sV[cur];
+
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      const int qn0 = q0 + ms * 16;
+      const int qy = qn0 / g.ws, qx0 = qn0 - qy * g.ws;
+#pragma unroll
+      for (int kbq = 0; kbq < 4 / SPK; ++kbq) {
+        uint4 ap;
+#pragma unroll
+        for (int hh = 0; hh < SPK; ++hh) {
+          // rows 4 fg + r of key strip ks: keys; column fr: this lane's query of strip ms
+          const int ks = kbq * SPK + hh;
+          f32x4 s, dp;
+#pragma unroll
+          for (int kb = 0; kb < KBQ; ++kb) {
+            const uint4 fk = frag<T>(cK, L::QROW, ks * 16, kb, HD, lane);
+            const uint4 fv = frag<T>(cV, L::QROW, ks * 16, kb, HD, lane);
+            if (kb == 0) { s = mma16z<T>(fk, fq[ms][0]); dp = mma16z<T>(fv, fo[ms][0]); }
+            else { mma16<T>(s, fk, fq[ms][kb]); mma16<T>(dp, fv, fo[ms][kb]); }
+          }
+          const int kn0 = kt * 64 + ks * 16;
+          const int ky = kn0 / g.ws, kx0 = kn0 - ky * g.ws;
+          const int j0 = kx0 + 4 * fg - qx0 - fr + g.ws - 1;       // reversed entries j0 .. j0 + 3 <-> keys 4 fg .. 4 fg + 3
+          const float4 b4 = *(const float4*)&myB[((qy - ky - dymin) * 4 + (j0 & 3)) * RL + (j0 & ~3)];
+          const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fast_exp2(fmaf(s[r], scale2, ba[r]) - lq[ms]);
+            dp[r] = p * (dp[r] - dl[ms]);
+          }
+          // bias gradient: dS[key 4 fg + r][query fr] belongs to dx = (qx0 + fr) - (kx0 + 4 fg + r).  LDS float atomics
+          // cost ~3 cycles per active lane, so the four keys of a lane are first summed along the diagonals of the tile
+          // inside the 16-lane row (key + 1 <-> query + 1 <-> next lane): lane fr ends with the diagonal
+          // dx0 + fr, dx0 = qx0 - kx0 - 4 fg; the six elements that fall off the low end are the diagonals
+          // dx0 - 3 .. dx0 - 1, collected in lanes 0..2 of `lo`.  76 instead of 256 atomic lanes per tile.
+          {
+            const float u = dp[0] + dpp_row_shl<1>(dp[1]) + dpp_row_shl<2>(dp[2]) + dpp_row_shl<3>(dp[3]);
+            const float lo = dp[3] + dpp_row_shr<1>(dp[2]) + dpp_row_shr<2>(dp[1]);
+            float* dbp = &sDB[(qy - ky + g.ws - 1) * L2 + (qx0 - kx0 - 4 * fg + g.ws - 1) + fr];
+            atomicAdd(dbp, u);
+            if (fr < 3) atomicAdd(dbp - 3, lo);
+          }
+          // dS strips leave the accumulators as the A operand of dQ += dS K (row = query fr, k-slots = keys)
+          if constexpr (std::is_same<T, bf16>::value) {
+            const uint32_t d01 = pack2bf(dp[0], dp[1]), d23 = pack2bf(dp[2], dp[3]);
+            if (hh == 0) { ap.x = d01; ap.y = d23; } else { ap.z = d01; ap.w = d23; }
+          } else {
+            ap = make_uint4(__float_as_uint(dp[0]), __float_as_uint(dp[1]), __float_as_uint(dp[2]), __float_as_uint(dp[3]));
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < DB; ++d) mma16<T>(dq[ms][d], ap, fragTp_fwd<T>(cK, L::QROW, kbq, d * 16, lane));
+      }
+    }
+    DQ_STORE(cur ^ 1)
+  }
+#undef DQ_ISSUE_ONE
+#undef DQ_ISSUE
+#undef DQ_STORE_ONE
+#undef DQ_STORE
+  // ---- bias gradient of the head; dQ staged through one of the four tiles, coalesced store
+  __syncthreads();
+  for (int i = tid; i < L2 * L2; i += 256) {
+    const float v = sDB[i];
+    if (v != 0.f) atomicAdd(dbias_t + (long)head * L2 * L2 + i, v);
+  }
+  unsigned char* st = sK[w >> 1] + (w & 1) * 32 * L::QROW;
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+        st_elem<T>(st + (ms * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dq[ms][d][r] * scale);
+  wave_sync();
+  for (int idx = lane; idx < 32 * L::DCH; idx += 64) {
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;
+    *(uint4*)(dqkv + (long)win_row0(g, b, wy, wx, q0 + r) * C3 + head * HD + dc * KPL) = *(const uint4*)(st + r * L::QROW + dc * 16);
+  }
+}
+
 bool make_geo(AttnGeo& g, int B, int H, int W, int C, int heads, int ws, int shift) {
   if (B <= 0 || H <= 0 || W <= 0 || ws <= 0 || (H % ws) || (W % ws) || heads <= 0 || (C % heads)) return false;
   if ((ws * ws) % 64) return false;
@@ -1684,6 +2065,15 @@ int launch_bwd(const void* qkv, const float* bias_t, const void* out, const void
     hipLaunchKernelGGL((attn_bwd_kernel<T, HD, NW, PFOK>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
                        (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin, 0);
   } else {
+    if constexpr (HD % TT<T>::MMA_K == 0 && Lay<T, HD>::DCH >= 4 && Lay<T, HD>::DCH <= 16) {
+      if (g.nqt > 1 && g.shift == 0 && g.ws <= 32 && (g.nqt % 4) == 0 && (g.N % 128) == 0) {   // two passes, no dQ atomics
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD>), dim3((unsigned)(nwin * g.heads * (g.N / 128))), dim3(256), 0, st,
+                           (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, g);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3((unsigned)(nwin * g.heads * (g.N / 128))), dim3(256), 0, st,
+                           (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, g);
+        return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+      }
+    }
     if (g.nqt > 1) {
       hipLaunchKernelGGL((attn_bwd_mt_kernel<T, HD, NW>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
                          (const T*)qkv, bias_t, (const T*)dout, lse, delta, (T*)dqkv, dbias_t, dq_acc, g, nwin);

@@ -170,6 +170,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// hand-over through LDS between lanes of ONE wave: a wave's LDS operations execute in order, so only the compiler has
+// to be told (no s_barrier)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // XCD-aware, bijective block remap (8 XCDs, blocks dealt round-robin): logical tiles
 // that are adjacent run on one XCD and share its L2.  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

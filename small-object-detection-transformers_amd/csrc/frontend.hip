@@ -109,14 +109,6 @@ __global__ __launch_bounds__(256) void frontend_fwd_kernel(const float* __restri
   }
 }
 
-// hand-over through LDS between lanes of ONE wave: a wave's LDS operations execute in order, only the compiler has to
-// be told
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // element e of a 16-byte chunk as f32
 template <typename T> __device__ __forceinline__ float chunk_elem(const uint4& u, int e);
 template <> __device__ __forceinline__ float chunk_elem<float>(const uint4& u, int e) {
@@ -229,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void frontend_bwd_kernel(const float* __res
     __syncthreads();   // previous iteration's readers are done
 #pragma unroll
     for (int k = 0; k < 16; ++k) sP[p][lane][k] = pt[k];
-    wave_lds_sync();                 // sP[p] is written and read by this wave only
+    wave_sync();                 // sP[p] is written and read by this wave only
     // E^T[ch][tok] = W[ch][tap] P^T[tap][tok] + bias: 3 x 4 tiles of exact-f32 MFMA 16x16x4, W and bias loop-invariant
     // in registers (the VALU stays free for the other workgroup's LayerNorm phase)
 #pragma unroll

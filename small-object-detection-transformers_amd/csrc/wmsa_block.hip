@@ -160,14 +160,6 @@ __device__ __forceinline__ float rows_max(float v) {
   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
-// wave-private LDS hand-over between lanes of ONE wave: LDS operations of a wave execute in order, so only the
-// compiler has to be told (no s_barrier)
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // token row (natural order) of window-local token n of window (b, wy, wx) after the cyclic shift (backbone_vit.py:1096)
 __device__ __forceinline__ int wtoken(const WArgs& a, int b, int wy, int wx, int n) {
   int y = wy * WWS + (n >> 3) + a.shift, x = wx * WWS + (n & 7) + a.shift;

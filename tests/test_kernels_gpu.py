@@ -419,7 +419,8 @@ def _attn_ref(qkv, table, B, H, W, Cc, heads, ws, shift):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("Cc,H,W,ws,shift", [(192, 16, 24, 8, 0), (192, 16, 24, 8, 2), (384, 16, 16, 8, 2),
-                                               (768, 32, 32, 32, 0), (768, 16, 32, 16, 0), (768, 32, 64, 32, 16)])
+                                               (768, 32, 32, 32, 0), (768, 16, 32, 16, 0), (768, 32, 64, 32, 16),
+                                               (384, 32, 32, 16, 0), (768, 64, 32, 32, 0)])
 def test_window_attention(ops, dev, dt, Cc, H, W, ws, shift):
     B, heads = 2, 12
     M = B * H * W
