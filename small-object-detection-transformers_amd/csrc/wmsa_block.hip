@@ -58,18 +58,24 @@ template <typename T> struct WL {
   static constexpr int CHL = NCH / 4;                    // chunks per lane and token in the (g, t) mapping: 6 / 12
   static constexpr int K16B = 4 * E;                     // bytes of a k16 operand per lane: 8 / 16
   static constexpr int WFRAG = KSTEPS * 1024;            // Wq_h (or Wk_h, Wv_h) in fragment order: 6 KB / 12 KB
-  static constexpr int WQ_OFF = 0, WK_OFF = WFRAG, WV_OFF = 2 * WFRAG, WP_OFF = 3 * WFRAG;
-  static constexpr int WPB = WHEADS * 64 * K16B;         // Wproj[:, h] as 12 n-strips of k16 operands: 6 KB / 12 KB
-  static constexpr int BIAS_OFF = WP_OFF + WPB;
+  static constexpr int WQ_OFF = 0, WK_OFF = WFRAG, WV_OFF = 2 * WFRAG;
+  static constexpr int BIAS_OFF = 3 * WFRAG;
   static constexpr int BIASB = 4 * 15 * 16 * E;          // four shifted copies of the head's [15][16] table (x log2 e)
   static constexpr int BQKV_OFF = BIAS_OFF + BIASB;      // bq[16] bk[16] bv[16] f32, padded to 256 bytes
-  static constexpr int STAGE = BQKV_OFF + 256;           // 26752 / 53248 bytes
-  static constexpr int TAIL_OFF = WHEADS * STAGE;        // bproj[192], g1, b1, g2, b2: f32
+  static constexpr int HEAD_BYTES = BQKV_OFF + 256;      // 20608 / 40960
+  // output projection: out^T = Wproj O^T contracts over all 192 attention channels AFTER the heads (O^T of the 12 heads
+  // stays packed in registers), so Wproj streams through the same stage ring as three more stages of four 16-row strips
+  // each: strip n, k-step kp = one 1 KB fragment (lane (g, t): row 16 n + t, 16 bytes of k)
+  static constexpr int KP = WC / KU;                     // k-steps of the projection: 6 (head pairs) / 12 (heads)
+  static constexpr int PROJ_BYTES = 4 * KP * 1024;       // 24576 / 49152
+  static constexpr int STAGE = PROJ_BYTES > HEAD_BYTES ? PROJ_BYTES : HEAD_BYTES;
+  static constexpr int NSTG = WHEADS + 3;                // stages per block: 12 heads + 3 projection stages
+  static constexpr int TAIL_OFF = NSTG * STAGE;          // bproj[192], g1, b1, g2, b2: f32
   static constexpr int PACK_BYTES = TAIL_OFF + 5 * WC * 4;
   static constexpr int XNB = 64 * ROWB;                  // one wave's LN1 tile: 24 KB / 48 KB
   static constexpr int VPB = 64 * WHD * E;               // v transposition patch: 2 KB / 4 KB
 };
-static_assert(WL<bf16>::STAGE == 26752 && WL<float>::STAGE == 53248, "stage layout");
+static_assert(WL<bf16>::STAGE == 24576 && WL<float>::STAGE == 49152, "stage layout");
 
 struct WArgs {
   const unsigned char* x; const unsigned char* wpk;
@@ -227,10 +233,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
   // barrier.  The DMA is inline asm: hipcc does not know a VMEM operation is writing LDS, so it neither waits vmcnt(0)
   // in front of the LDS accesses it can see nor reorders them (memory clobber).  Single-buffered (f32 parity path): a
   // plain copy loop between two barriers.
-  static_assert(NST == 1 || NPF == 7, "seven 4 KB slices per stage");
-#define PF_ISSUE(BUF, HEAD)                                                             \
+  static_assert(NST == 1 || NPF == 6, "six 4 KB slices per stage");
+#define PF_ISSUE(BUF, STG)                                                              \
   if constexpr (NST == 2) {                                                             \
-    const unsigned char* gsrc_ = a.wpk + (unsigned)((HEAD) * L::STAGE);                 \
+    const unsigned char* gsrc_ = a.wpk + (unsigned)((STG) * L::STAGE);                  \
     const unsigned ldst_ = smem0 + SST0 + (unsigned)((BUF) * L::STAGE) + (unsigned)(w * 1024); \
     const unsigned voff_ = (unsigned)(tid * 16);                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) {                                \
@@ -240,9 +246,19 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
     }                                                                                   \
   }
 #define PF_WAIT() do { if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
-#define PF_COPY(HEAD)                                                                   \
+  // The stage DMA of head h + 1 is issued at the top of head h, BEFORE that head's save-for-backward stores (q, k: 8, v: 2,
+  // lse: 4, attention output: 4 VMEM instructions per wave).  VMEM operations retire in issue order, so "at most
+  // NSAVE_KEEP outstanding" means the DMA has landed while the youngest stores stay in flight across the hand-over
+  // barrier instead of being waited for (~2K cycles per head).  NSAVE_KEEP is two below the 18 issued: a wait that
+  // keeps FEWER operations than were issued after the DMA only over-waits.
+  constexpr int NSAVE_KEEP = 16;
+  static_assert(8 + L::VPB / 1024 + 4 + 4 >= NSAVE_KEEP + 2 || !SAVE || NST == 1, "stores per head");
+#define PF_WAIT_KEEP_STORES(COND) do { if constexpr (NST == 2) {                        \
+    if (SAVE && (COND)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");               \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } } while (0)
+#define PF_COPY(STG)                                                                    \
   if constexpr (NST == 1) {                                                             \
-    const uint4* src_ = (const uint4*)(a.wpk + (unsigned)((HEAD) * L::STAGE));          \
+    const uint4* src_ = (const uint4*)(a.wpk + (unsigned)((STG) * L::STAGE));           \
     uint4* dst_ = (uint4*)(smem + SST0);                                                \
     for (int idx_ = tid; idx_ < NCHK; idx_ += NT) dst_[idx_] = src_[idx_];              \
   }
@@ -375,93 +391,81 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
 
     STAMP_TO(6);
     // ================= the 12 heads
-    f32x4 outT[WHEADS][4];                               // out^T: [n strip][token strip], row = channel 16 n + 4 g + r, column = token t
-#pragma unroll
-    for (int n = 0; n < WHEADS; ++n)
-#pragma unroll
-      for (int ms = 0; ms < 4; ++ms) outT[n][ms] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // O^T of every head stays packed in registers (one k16 operand per token strip): the output projection contracts
+    // over all 192 channels after the loop with full-depth MFMAs, and the head loop runs without the 192 out^T accumulators
+    k16_t poall[WHEADS][4];
 
     for (int h = 0; h < WHEADS; ++h) {
       const int buf = NST == 2 ? (sidx & 1) : 0;
       STAMP_TO(5);
-      PF_WAIT();                                         // this wave's slices of stage `buf` have landed
+      PF_WAIT_KEEP_STORES(valid && h > 0);               // this wave's slices of stage `buf` have landed
       __syncthreads();                                   // stage `buf` is complete; everyone has left the other buffer
       STAMP_TO(0);
       const unsigned sbo = SST0 + (unsigned)(buf * L::STAGE);      // this head's stage
-      const unsigned wb16 = smem0 + sbo + l16, wbk = smem0 + sbo + lk16;
+      const unsigned wb16 = smem0 + sbo + l16;
       const unsigned bb3 = smem0 + sbo + (unsigned)bias_lane_off - (unsigned)(3 * 2 * 16 * E);       // strip difference -3
       const unsigned sbg = smem0 + sbo + (unsigned)(16 * g), sbt = smem0 + sbo + (unsigned)(4 * t);
-      const int hnext = h + 1 == WHEADS ? 0 : h + 1;
-      PF_ISSUE(buf ^ 1, hnext)
+      PF_ISSUE(buf ^ 1, h + 1)                           // (stage 12 = first projection stage follows head 11)
 
       auto body = [&](auto MSK_) {
         constexpr bool MSK = decltype(MSK_)::value;
         // ---- q^T, k^T (channel rows, token columns) and v (token rows, channel columns) of this head.
         // LDS issue order: q/k/v bias (3) + table entries (7), fragments of k-step 0 (7), then per k-step the fragments of
-        // the next one (7) - or, at the last, this head's Wproj slice (12) - BEFORE the 12 MFMAs of the current step.
+        // the next one (7) BEFORE the 12 MFMAs of the current step.
         typedef typename KR<T>::type kreg_t;
         u32x4_ bqr = lds_rd128a<L::BQKV_OFF>(sbg), bkr = lds_rd128a<L::BQKV_OFF + 64>(sbg);
         unsigned bvr = lds_rd32a<L::BQKV_OFF + 128>(sbt);
         kreg_t biar[7];
         static_for<0, 7>([&](auto d_) { constexpr int d = decltype(d_)::value; biar[d] = KR<T>::template rd<d * 2 * 16 * E>(bb3); });
-        // two passes over the token strips (pairs 0-1, 2-3): 24 instead of 48 transient accumulator registers beside the 192
-        // of out^T (the Wq/Wk/Wv fragments are read twice: +18 LDS reads per head)
-        u32x4_ wf[2][3], xf[2][2];
-        kreg_t wpr[WHEADS];
-        constexpr int NSTEP = 2 * L::KSTEPS;             // step = (strip pair, k-step)
-        auto issue_k = [&](auto st_) {
-          constexpr int st = decltype(st_)::value, bsel = st & 1, hp = st / L::KSTEPS, kk = st % L::KSTEPS;
+        u32x4_ wf[2][3], xf[2][4];
+        auto issue_k = [&](auto kk_) {
+          constexpr int kk = decltype(kk_)::value, bsel = kk & 1;
           wf[bsel][0] = lds_rd128a<L::WQ_OFF + kk * 1024>(wb16);
           wf[bsel][1] = lds_rd128a<L::WK_OFF + kk * 1024>(wb16);
           wf[bsel][2] = lds_rd128a<L::WV_OFF + kk * 1024>(wb16);
-          xf[bsel][0] = lds_rd128a<(2 * hp) * 16 * L::ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
-          xf[bsel][1] = lds_rd128a<(2 * hp + 1) * 16 * L::ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
+          static_for<0, 4>([&](auto ms_) {
+            constexpr int ms = decltype(ms_)::value;
+            xf[bsel][ms] = lds_rd128a<ms * 16 * L::ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
+          });
         };
         issue_k(std::integral_constant<int, 0>{});
         k16_t pq[4], pkk[4], pv[4];
-        f32x4 qT[2], kT[2], vv[2];
-        f32x4 bqv, bkv;
-        float bvs = 0.f;
-        static_for<0, NSTEP>([&](auto st_) {
-          constexpr int st = decltype(st_)::value, bsel = st & 1, hp = st / L::KSTEPS, kk = st % L::KSTEPS;
-          if constexpr (st + 1 < NSTEP) {
-            issue_k(std::integral_constant<int, st + 1>{});
-            LDS_WAIT(5);
+        f32x4 qT[4], kT[4], vv[4];
+        static_for<0, L::KSTEPS>([&](auto kk_) {
+          constexpr int kk = decltype(kk_)::value, bsel = kk & 1;
+          if constexpr (kk + 1 < L::KSTEPS) {
+            issue_k(std::integral_constant<int, kk + 1>{});
+            LDS_WAIT(7);
           } else {
-            static_for<0, WHEADS / 2>([&](auto n_) { constexpr int n = decltype(n_)::value; wpr[n] = KR<T>::template rd<L::WP_OFF + n * 64 * L::K16B>(wbk); });
-            LDS_WAIT(6);
+            LDS_WAIT(0);
           }
           LDS_DEP(wf[bsel][0]); LDS_DEP(wf[bsel][1]); LDS_DEP(wf[bsel][2]);
-          LDS_DEP(xf[bsel][0]); LDS_DEP(xf[bsel][1]);
-          if constexpr (st == 0) {
-            LDS_DEP(bqr); LDS_DEP(bkr); LDS_DEP(bvr);
-            bqv = KR<float>::f4(bqr); bkv = KR<float>::f4(bkr);
-            bvs = __uint_as_float(bvr);
-          }
+          LDS_DEP(xf[bsel][0]); LDS_DEP(xf[bsel][1]); LDS_DEP(xf[bsel][2]); LDS_DEP(xf[bsel][3]);
           if constexpr (kk == 0) {
+            LDS_DEP(bqr); LDS_DEP(bkr); LDS_DEP(bvr);
+            const f32x4 bqv = KR<float>::f4(bqr), bkv = KR<float>::f4(bkr);
+            const float bvs = __uint_as_float(bvr);
 #pragma unroll
-            for (int ml = 0; ml < 2; ++ml) { qT[ml] = bqv; kT[ml] = bkv; vv[ml] = f32x4{bvs, bvs, bvs, bvs}; }
+            for (int ms = 0; ms < 4; ++ms) { qT[ms] = bqv; kT[ms] = bkv; vv[ms] = f32x4{bvs, bvs, bvs, bvs}; }
           }
           const uint4 wq = u4(wf[bsel][0]), wk = u4(wf[bsel][1]), wv = u4(wf[bsel][2]);
 #pragma unroll
-          for (int ml = 0; ml < 2; ++ml) {
-            const uint4 x4 = u4(xf[bsel][ml]);
-            mma16<T>(qT[ml], wq, x4);
-            mma16<T>(kT[ml], wk, x4);
-            mma16<T>(vv[ml], x4, wv);
-          }
-          if constexpr (kk == L::KSTEPS - 1) {
-#pragma unroll
-            for (int ml = 0; ml < 2; ++ml) {
-              pq[2 * hp + ml] = pk16<T>(qT[ml]); pkk[2 * hp + ml] = pk16<T>(kT[ml]); pv[2 * hp + ml] = pk16<T>(vv[ml]);
-              if constexpr (SAVE) {     // v -> [token][16] patch (the accumulator holds four tokens of ONE channel per lane)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  *(__attribute__((address_space(3))) T*)(p_vpw + (16 * (2 * hp + ml) + r) * WHD * E) = from_f<T>(vv[ml][r]);
-              }
-            }
+          for (int ms = 0; ms < 4; ++ms) {
+            const uint4 x4 = u4(xf[bsel][ms]);
+            mma16<T>(qT[ms], wq, x4);
+            mma16<T>(kT[ms], wk, x4);
+            mma16<T>(vv[ms], x4, wv);
           }
         });
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          pq[ms] = pk16<T>(qT[ms]); pkk[ms] = pk16<T>(kT[ms]); pv[ms] = pk16<T>(vv[ms]);
+          if constexpr (SAVE) {     // v -> [token][16] patch (the accumulator holds four tokens of ONE channel per lane)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *(__attribute__((address_space(3))) T*)(p_vpw + (16 * ms + r) * WHD * E) = from_f<T>(vv[ms][r]);
+          }
+        }
         STAMP_TO(1);
         if (save && valid) {
           unsigned char* qb = a.qkvw + (size_t)(whoff + h) * (3 * 64 * WHD * E);     // uniform
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
             (a.lsew + (size_t)(whoff + h) * 64)[16 * ms + t] = mx * (1.0f / WMSA_LOG2E) + __logf(sum);
         }
         STAMP_TO(3);
-        // ---- O^T = V^T P^T: row = channel 4 g + r, column = query; then out^T += Wproj[:, h] O^T
+        // ---- O^T = V^T P^T: row = channel 4 g + r, column = query
         k16_t po[4];
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
@@ -540,26 +544,60 @@ __global__ __launch_bounds__(NWV * 64, 1) void wmsa_block_kernel(const WArgs a) 
             *(k16_t*)(a.ao + (size_t)(WHD * h * E) + ao_off) = po[ms];
           }
         }
-        // Wproj slice: n-strips 0-5 were requested under the last QKV step; 6-11 are requested now and land under the first
-        // 24 MFMAs (fewer fragment registers alive across the softmax)
-        static_for<WHEADS / 2, WHEADS>([&](auto n_) { constexpr int n = decltype(n_)::value; wpr[n] = KR<T>::template rd<L::WP_OFF + n * 64 * L::K16B>(wbk); });
-        LDS_WAIT(6);
+        // park O^T of head h (a uniform switch: a register array cannot be indexed by the loop counter)
+        static_for<0, WHEADS>([&](auto hh_) {
+          constexpr int hh = decltype(hh_)::value;
+          if (h == hh) {
 #pragma unroll
-        for (int n = 0; n < WHEADS; ++n) {
-          if (n == WHEADS / 2) LDS_WAIT(0);
-          LDS_DEP(wpr[n]);
-          const k16_t wp = KR<T>::op(wpr[n]);
-#pragma unroll
-          for (int ms = 0; ms < 4; ++ms) mmak16(outT[n][ms], wp, po[ms]);
-        }
+            for (int ms = 0; ms < 4; ++ms) poall[hh][ms] = po[ms];
+          }
+        });
       };
       if (msk) body(std::true_type{}); else body(std::false_type{});
       STAMP_TO(4);
 
       if (NST == 1) __syncthreads();                     // single buffer: everyone is done reading before it is refilled
-      PF_COPY(hnext)
+      PF_COPY(h + 1)
       ++sidx;
     }
+
+    // ================= output projection: out^T = Wproj O^T, three stages of four 16-channel strips
+    f32x4 outT[WHEADS][4];                               // out^T: [n strip][token strip], row = channel 16 n + 4 g + r, column = token t
+    static_for<0, 3>([&](auto ps_) {
+      constexpr int ps = decltype(ps_)::value;
+      const int buf = NST == 2 ? (sidx & 1) : 0;
+      STAMP_TO(4);
+      PF_WAIT_KEEP_STORES(valid && ps == 0);             // (stage 12 was requested at the top of head 11)
+      __syncthreads();
+      STAMP_TO(0);
+      const unsigned pb16 = smem0 + SST0 + (unsigned)(buf * L::STAGE) + l16;
+      PF_ISSUE(buf ^ 1, (ps == 2 ? 0 : WHEADS + 1 + ps))  // after the last projection stage: head 0 of the next window group
+      u32x4_ af[2];
+      af[0] = lds_rd128a<0>(pb16);
+      static_for<0, 4 * L::KP>([&](auto i_) {
+        constexpr int i = decltype(i_)::value, nl = i / L::KP, kp = i % L::KP, n = 4 * ps + nl;
+        if constexpr (i + 1 < 4 * L::KP) {
+          af[(i + 1) & 1] = lds_rd128a<(i + 1) * 1024>(pb16);
+          LDS_WAIT(1);
+        } else {
+          LDS_WAIT(0);
+        }
+        LDS_DEP(af[i & 1]);
+        const uint4 wa = u4(af[i & 1]);
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          uint4 ob;
+          if constexpr (std::is_same<T, bf16>::value)
+            ob = make_uint4(poall[2 * kp][ms].x, poall[2 * kp][ms].y, poall[2 * kp + 1][ms].x, poall[2 * kp + 1][ms].y);
+          else
+            ob = poall[kp][ms];
+          if constexpr (kp == 0) outT[n][ms] = mma16z<T>(wa, ob); else mma16<T>(outT[n][ms], wa, ob);
+        }
+      });
+      if (NST == 1) __syncthreads();
+      PF_COPY((ps == 2 ? 0 : WHEADS + 1 + ps))
+      ++sidx;
+    });
 
     STAMP_TO(5);
     // ================= epilogue: x_mid = x + (out + bproj), xn2 = LN2(x_mid)
@@ -677,6 +715,20 @@ __global__ __launch_bounds__(256) void wmsa_pack_kernel(const float* __restrict_
     }
     return;
   }
+  if (h > WHEADS) {
+    // projection stage ps: strips n = 4 ps .. 4 ps + 3, fragment (n, kp): lane (g, t) = row 16 n + t, KPL consecutive k
+    // slots; bf16: slots j < 4 <-> channel 32 kp + 4 g + j (head 2 kp), j >= 4 <-> 32 kp + 16 + 4 g + (j - 4) (head 2 kp + 1),
+    // the order in which two k16 O^T operands concatenate; f32: channel 16 kp + 4 g + j
+    const int ps = h - WHEADS - 1;
+    T* dst = (T*)(wpk + (long)(WHEADS + ps) * L::STAGE);
+    for (int e = tid; e < 4 * L::KP * 64 * KPL; e += 256) {
+      const int frag = e / (64 * KPL), l = (e / KPL) % 64, j = e % KPL;
+      const int nl = frag / L::KP, kp = frag % L::KP, n = 4 * ps + nl;
+      const int ch = KPL == 8 ? 32 * kp + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3) : 16 * kp + 4 * (l >> 4) + j;
+      dst[e] = from_f<T>(proj_w[(long)(16 * n + (l & 15)) * WC + ch]);
+    }
+    return;
+  }
   unsigned char* sb = wpk + (long)h * L::STAGE;
   // Wq_h / Wk_h / Wv_h in fragment order: [k-step][lane][KPL], lane (g, t) = row 16 h + t, columns KU kk + KPL g + j
   for (int sect = 0; sect < 3; ++sect) {
@@ -684,14 +736,6 @@ __global__ __launch_bounds__(256) void wmsa_pack_kernel(const float* __restrict_
     for (int e = tid; e < L::KSTEPS * 64 * KPL; e += 256) {
       const int kk = e / (64 * KPL), l = (e / KPL) % 64, j = e % KPL;
       dst[e] = from_f<T>(qkv_w[(long)(sect * WC + WHD * h + (l & 15)) * WC + KU * kk + KPL * (l >> 4) + j]);
-    }
-  }
-  // Wproj[:, 16 h .. 16 h + 15] as 12 n-strips of k16 operands: lane (g, t) = row 16 n + t, columns 16 h + 4 g + j
-  {
-    T* dst = (T*)(sb + L::WP_OFF);
-    for (int e = tid; e < WHEADS * 64 * 4; e += 256) {
-      const int n = e / 256, l = (e / 4) % 64, j = e % 4;
-      dst[e] = from_f<T>(proj_w[(long)(16 * n + (l & 15)) * WC + WHD * h + 4 * (l >> 4) + j]);
     }
   }
   // relative-position bias of this head x log2 e: copy v, row dyi, position i holds table[dyi][14 - (i + v)]
@@ -747,10 +791,10 @@ extern "C" int sodt_wmsa_pack(const float* qkv_w, const float* qkv_b, const floa
   if (C != WC || heads != WHEADS || ws != WWS) return SODT_EINVAL;
   hipStream_t st = (hipStream_t)st_;
   if (dtype == SODT_BF16)
-    hipLaunchKernelGGL(wmsa_pack_kernel<bf16>, dim3(WHEADS + 1), dim3(256), 0, st, qkv_w, qkv_b, proj_w, proj_b, rpb_table,
+    hipLaunchKernelGGL(wmsa_pack_kernel<bf16>, dim3(WHEADS + 4), dim3(256), 0, st, qkv_w, qkv_b, proj_w, proj_b, rpb_table,
                        n1_w, n1_b, n2_w, n2_b, (unsigned char*)wpk);
   else if (dtype == SODT_F32)
-    hipLaunchKernelGGL(wmsa_pack_kernel<float>, dim3(WHEADS + 1), dim3(256), 0, st, qkv_w, qkv_b, proj_w, proj_b, rpb_table,
+    hipLaunchKernelGGL(wmsa_pack_kernel<float>, dim3(WHEADS + 4), dim3(256), 0, st, qkv_w, qkv_b, proj_w, proj_b, rpb_table,
                        n1_w, n1_b, n2_w, n2_b, (unsigned char*)wpk);
   else
     return SODT_EINVAL;
