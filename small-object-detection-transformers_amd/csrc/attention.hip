@@ -2030,12 +2030,23 @@ int launch_fwd(const void* qkv, const float* bias_t, void* out, float* lse, cons
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
+// Grid of the persistent single-tile backward kernels: every workgroup ends with one flush of its bias-gradient table
+// (225 global atomics per wave onto the 2,700 floats of the 12 heads).  With 1024 x (heads / NW) workgroups that was
+// 2.7 M same-line device-scope atomics per launch - 0.2 ms, 40 % of the stage-1 launch (the loops themselves ran six
+// rounds of 0.05 ms).  Launch only as many workgroups as are resident at once and let them walk more windows.
+int bwd_persistent_grid(int nwin, int ngroups, int NW) {
+  const int resident = 256 * (NW == 4 ? 2 : (NW == 2 ? 2 : 4));     // CUs x workgroups per CU (launch bounds / LDS)
+  int gx = resident / (ngroups > 0 ? ngroups : 1);
+  if (gx < 1) gx = 1;
+  return nwin < gx ? nwin : gx;
+}
+
 template <typename T, int HD, int NW>
 int launch_bwd_wm(const void* qkvw, const float* bias_t, const void* dout, const float* lsew, void* dqkv,
                   float* dbias_t, const AttnGeo& g, hipStream_t st) {
   if (g.heads % NW || g.nqt != 1 || g.ws != 8) return SODT_EINVAL;
   const int nwin = g.B * g.nwy * g.nwx;
-  const int gx = nwin < 1024 ? nwin : 1024;
+  const int gx = bwd_persistent_grid(nwin, g.heads / NW, NW);
   hipLaunchKernelGGL((attn_bwd_fast2_kernel<T, HD, NW, true>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
                      (const T*)qkvw, bias_t, (const T*)dout, lsew, (T*)dqkv, dbias_t, g, nwin);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
@@ -2057,6 +2068,7 @@ int launch_bwd(const void* qkv, const float* bias_t, const void* out, const void
   int gx = nitems < 1024 ? nitems : 1024;
   constexpr bool PFOK = (4 * Lay<T, HD>::DCH <= 16);
   if (PFOK && g.nqt == 1 && g.ws == 8) {
+    gx = bwd_persistent_grid(nwin, g.heads / NW, NW);
     if constexpr (PFOK) {
       hipLaunchKernelGGL((attn_bwd_fast2_kernel<T, HD, NW>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
                          (const T*)qkv, bias_t, (const T*)dout, lse, (T*)dqkv, dbias_t, g, nwin);
