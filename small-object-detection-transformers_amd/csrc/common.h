@@ -144,9 +144,21 @@ template <> __device__ __forceinline__ float gelu_t<bf16>(float x) {
 }
 template <typename T> __device__ __forceinline__ float dgelu_t(float x);
 template <> __device__ __forceinline__ float dgelu_t<float>(float x) { return dgelu_f(x); }
+// gelu'(x) - 1/2 = erf(x / sqrt 2) / 2 + x phi(x) is odd: one degree-15 odd minimax polynomial of the argument clamped to
+// [-4, 4] (|err| <= 2.8e-4 evaluated in f32; gelu'(+-4) = 0.5 +- 0.4995) - 11 FMA-pipe operations instead of the erf
+// polynomial plus an exp2 (the epilogues that multiply by gelu' were VALU-bound: -0.33 ms of 1.7 on the stage-1 launches)
 template <> __device__ __forceinline__ float dgelu_t<bf16>(float x) {
-  const float gauss = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);       // exp(-x^2 / 2)
-  return fmaf(0.5f, erf_poly(x), fmaf(x * 0.3989422804014327f, gauss, 0.5f));
+  const float z = fminf(fmaxf(x, -4.0f), 4.0f);
+  const float u = z * z;
+  float p = -1.642114889e-08f;
+  p = fmaf(p, u, 1.213881774e-06f);
+  p = fmaf(p, u, -3.846123582e-05f);
+  p = fmaf(p, u, 6.876639673e-04f);
+  p = fmaf(p, u, -7.687550504e-03f);
+  p = fmaf(p, u, 5.591514707e-02f);
+  p = fmaf(p, u, -2.620302439e-01f);
+  p = fmaf(p, u, 7.967218161e-01f);
+  return fmaf(p, z, 0.5f);
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
