@@ -1993,6 +1993,183 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
   }
 }
 
+// ---------------------------------------------------------------------------------
+// forward, unshifted windows of more than 64 tokens, second generation (same machinery as attn_bwd_dq_kernel): one
+// workgroup = four waves = four 64-query tiles of ONE (window, head); Q fragments live in registers, the 64-key K / V
+// tiles are double buffered in LDS and shared, the bias of a 16 x 16 tile is ONE aligned 16-byte LDS load per lane from
+// the shifted-copy staging (attn_fwd_mt_kernel gathers one table entry per element through three LDS reads and ~10
+// integer operations: its softmax, not its MFMAs, set its 0.44 ms), online-softmax statistics cross the four 16-lane
+// rows with v_permlane swaps instead of ds_bpermute.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float rows4_sum(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows4_max(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_mt2_kernel(
+    const T* __restrict__ qkv, const float* __restrict__ bias_t, T* __restrict__ out, float* __restrict__ lse, const AttnGeo g) {
+  using L = Lay<T, HD>;
+  constexpr int E = L::E, KPL = L::KPL, MK = TT<T>::MMA_K, SPK = MK / 16, KBQ = L::KBQ, DB = HD / 16;
+  constexpr int NPF = 64 * L::DCH / 256;
+  static_assert(HD % MK == 0 && NPF >= 1 && NPF <= 4, "head_dim");
+  __shared__ __attribute__((aligned(16))) unsigned char sK[2][L::QTILE], sV[2][L::QTILE];
+  __shared__ __attribute__((aligned(16))) float sBias[4][BWD2_BT];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nqg = g.nqt / 4;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qg = bid % nqg; bid /= nqg;
+  const int head = bid % g.heads; bid /= g.heads;
+  const int wx = bid % g.nwx; bid /= g.nwx;
+  const int wy = bid % g.nwy; const int b = bid / g.nwy;
+  const int qt = qg * 4 + w;
+  const int C3 = 3 * g.C, L2 = 2 * g.ws - 1, RL = 2 * g.ws;
+  const int Rq = g.ws >= 64 ? 1 : 64 / g.ws;
+  const float scale2 = rsqrtf((float)HD) * SODT_LOG2E;
+  const float* bt = bias_t + (long)head * L2 * L2;
+  float* myB = sBias[w];
+
+  uint4 fq[4][KBQ];                                  // B operands of S^T = K Q^T (lane: query fr of strip ms)
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) {
+    const long row = win_row0(g, b, wy, wx, qt * 64 + ms * 16 + fr);
+#pragma unroll
+    for (int kb = 0; kb < KBQ; ++kb) fq[ms][kb] = *(const uint4*)(qkv + row * C3 + head * HD + kb * MK + KPL * fg);
+  }
+  float m_run[4], l_run[4];
+  f32x4 o[4][DB];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) {
+    m_run[ms] = -1e30f; l_run[ms] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) o[ms][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  uint4 pk0, pk1, pk2, pk3, pv0, pv1, pv2, pv3;
+#define F2_ISSUE_ONE(i, KT_)                                                            \
+  if constexpr (NPF > i) {                                                              \
+    const int idx = tid + i * 256;                                                      \
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;                                  \
+    const T* src = qkv + (long)win_row0(g, b, wy, wx, (KT_) * 64 + r) * C3 + head * HD + dc * KPL; \
+    pk##i = *(const uint4*)(src + g.C); pv##i = *(const uint4*)(src + 2 * g.C);         \
+  }
+#define F2_ISSUE(KT_) { F2_ISSUE_ONE(0, KT_) F2_ISSUE_ONE(1, KT_) F2_ISSUE_ONE(2, KT_) F2_ISSUE_ONE(3, KT_) }
+#define F2_STORE_ONE(i, BUF_)                                                           \
+  if constexpr (NPF > i) {                                                              \
+    const int idx = tid + i * 256;                                                      \
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;                                  \
+    *(uint4*)(sK[BUF_] + r * L::QROW + dc * 16) = pk##i; *(uint4*)(sV[BUF_] + r * L::QROW + dc * 16) = pv##i; \
+  }
+#define F2_STORE(BUF_) { F2_STORE_ONE(0, BUF_) F2_STORE_ONE(1, BUF_) F2_STORE_ONE(2, BUF_) F2_STORE_ONE(3, BUF_) }
+  F2_ISSUE(0)
+  F2_STORE(0)
+
+  const int qy0 = (qt * 64) / g.ws;
+  for (int kt = 0; kt < g.nqt; ++kt) {
+    const int cur = kt & 1;
+    __syncthreads();
+    { const int nk_ = kt + 1 < g.nqt ? kt + 1 : kt; F2_ISSUE(nk_) }
+    const int ky0 = (kt * 64) / g.ws;
+    const int dymin = qy0 - ky0 - (Rq - 1);
+    stage_bias_rows<true>(myB, bt, g.ws, dymin, 2 * Rq - 1, lane);
+    wave_sync();
+    const unsigned char* cK = sK[cur]; const unsigned char* cV = sV[cur];
+
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      // S^T strip: keys on rows (4 fg + r of key strip ks), this lane's query = 16 ms + fr
+      f32x4 s[4];
+#pragma unroll
+      for (int kb = 0; kb < KBQ; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const uint4 fk = frag<T>(cK, L::QROW, ks * 16, kb, HD, lane);
+          if (kb == 0) s[ks] = mma16z<T>(fk, fq[ms][0]); else mma16<T>(s[ks], fk, fq[ms][kb]);
+        }
+      const int qn0 = qt * 64 + ms * 16;
+      const int qy = qn0 / g.ws, qx0 = qn0 - qy * g.ws;
+      float mx = -1e30f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int kn0 = kt * 64 + ks * 16;
+        const int ky = kn0 / g.ws, kx0 = kn0 - ky * g.ws;
+        const int j0 = kx0 + 4 * fg - qx0 - fr + g.ws - 1;         // reversed entries j0 .. j0 + 3 <-> keys 4 fg .. 4 fg + 3
+        const float4 b4 = *(const float4*)&myB[((qy - ky - dymin) * 4 + (j0 & 3)) * RL + (j0 & ~3)];
+        const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[ks][r] = fmaf(s[ks][r], scale2, ba[r]); mx = fmaxf(mx, s[ks][r]); }
+      }
+      mx = rows4_max(mx);
+      const float mnew = fmaxf(m_run[ms], mx);
+      const float alpha = fast_exp2(m_run[ms] - mnew);
+      float sum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float p = fast_exp2(s[ks][r] - mnew); s[ks][r] = p; sum += p; }
+      sum = rows4_sum(sum);
+      l_run[ms] = l_run[ms] * alpha + sum;
+      m_run[ms] = mnew;
+      // rescale O rows (row 4 fg + r of strip ms <-> query column 4 fg + r, held by lane 4 fg + r of every row)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ar = __shfl(alpha, 4 * fg + r);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) o[ms][d][r] *= ar;
+      }
+      // O[ms] += P V: P strips straight from the accumulators (A operand: row = query fr, k-slots = keys)
+#pragma unroll
+      for (int kbq = 0; kbq < 4 / SPK; ++kbq) {
+        uint4 ap;
+        if constexpr (std::is_same<T, bf16>::value) {
+          ap = make_uint4(pack2bf(s[2 * kbq][0], s[2 * kbq][1]), pack2bf(s[2 * kbq][2], s[2 * kbq][3]),
+                          pack2bf(s[2 * kbq + 1][0], s[2 * kbq + 1][1]), pack2bf(s[2 * kbq + 1][2], s[2 * kbq + 1][3]));
+        } else {
+          ap = make_uint4(__float_as_uint(s[kbq][0]), __float_as_uint(s[kbq][1]), __float_as_uint(s[kbq][2]), __float_as_uint(s[kbq][3]));
+        }
+#pragma unroll
+        for (int d = 0; d < DB; ++d) mma16<T>(o[ms][d], ap, fragTp_fwd<T>(cV, L::QROW, kbq, d * 16, lane));
+      }
+    }
+    F2_STORE(cur ^ 1)
+  }
+#undef F2_ISSUE_ONE
+#undef F2_ISSUE
+#undef F2_STORE_ONE
+#undef F2_STORE
+  // ---- normalise, lse, stage O through one of the four tiles, coalesced store
+  __syncthreads();
+  unsigned char* st = w < 2 ? sK[w] : sV[w - 2];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) {
+    const float inv = __builtin_amdgcn_rcpf(l_run[ms]);
+    if (fg == 0 && lse)
+      lse[(long)win_row0(g, b, wy, wx, qt * 64 + ms * 16 + fr) * g.heads + head] = m_run[ms] * (1.0f / SODT_LOG2E) + __logf(l_run[ms]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ir = __shfl(inv, 4 * fg + r);
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+        st_elem<T>(st + (ms * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, o[ms][d][r] * ir);
+    }
+  }
+  wave_sync();
+  for (int idx = lane; idx < 64 * L::DCH; idx += 64) {
+    const int r = idx / L::DCH, dc = idx - r * L::DCH;
+    *(uint4*)(out + (long)win_row0(g, b, wy, wx, qt * 64 + r) * g.C + head * HD + dc * KPL) = *(const uint4*)(st + r * L::QROW + dc * 16);
+  }
+}
+
 bool make_geo(AttnGeo& g, int B, int H, int W, int C, int heads, int ws, int shift) {
   if (B <= 0 || H <= 0 || W <= 0 || ws <= 0 || (H % ws) || (W % ws) || heads <= 0 || (C % heads)) return false;
   if ((ws * ws) % 64) return false;
@@ -2013,6 +2190,14 @@ int launch_fwd(const void* qkv, const float* bias_t, void* out, float* lse, cons
       const int gx = nwin < 512 ? nwin : 512;
       hipLaunchKernelGGL((attn_fwd_fast_kernel<T, HD, NW>), dim3(gx, g.heads / NW), dim3(NW * 64), 0, st,
                          (const T*)qkv, bias_t, (T*)out, lse, g, nwin);
+      return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+    }
+  }
+  if constexpr (HD % TT<T>::MMA_K == 0 && Lay<T, HD>::DCH >= 4 && Lay<T, HD>::DCH <= 16) {
+    if (g.nqt > 1 && (g.nqt % 4) == 0 && g.shift == 0 && g.ws <= 64) {
+      const long nb = (long)g.B * g.nwy * g.nwx * (g.nqt / 4) * g.heads;
+      hipLaunchKernelGGL((attn_fwd_mt2_kernel<T, HD>), dim3((unsigned)nb), dim3(256), 0, st,
+                         (const T*)qkv, bias_t, (T*)out, lse, g);
       return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
     }
   }
