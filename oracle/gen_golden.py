@@ -338,6 +338,29 @@ def nms_goldens(out):
         print(f"[pin] NMS B={B} N={N} nc={nc} conf={conf} multi_label={ml}: kept {[int(a.shape[0]) for a in ref]} identical")
         cases.append(dict(B=B, N=N, nc=nc, conf=conf, iou=iou, multi_label=ml, agnostic=agn, classes=classes, seed=seed,
                           out=[a.clone() for a in ref], index=[i.clone() for i in idx]))
+    # autolabelling rows (general.py:451-458, `save_hybrid` in test.py:143-145): labels appended after the confidence filter
+    for (B, N, nc, conf, iou, ml, seed) in [(2, 1200, 8, 0.25, 0.45, True, 7), (2, 300, 8, 0.5, 0.45, False, 8)]:
+        z = R.synthetic_predictions(B, N, nc, seed=seed)
+        gl = torch.Generator().manual_seed(seed)
+        lab = []
+        for b in range(B):
+            nl = 6 if b == 0 else 0                      # second image: no labels
+            l = torch.zeros(nl, 5)
+            if nl:
+                l[:, 0] = torch.randint(0, nc, (nl,), generator=gl).float()
+                l[:3, 1:5] = z[b, :3, :4]                # three labels on top of predictions (they suppress / merge)
+                l[3:, 1:3] = torch.rand(nl - 3, 2, generator=gl) * 900 + 50
+                l[3:, 3:5] = torch.rand(nl - 3, 2, generator=gl) * 40 + 10
+            lab.append(l)
+        ref = G.non_max_suppression(z.clone(), conf, iou, multi_label=ml, labels=lab)
+        mine, idx = R.non_max_suppression(z.clone(), conf, iou, multi_label=ml, return_index=True, labels=lab)
+        for a, b in zip(ref, mine):
+            assert a.shape == b.shape, (a.shape, b.shape)
+            if a.numel():
+                assert maxdiff(a, b) < 1e-3, maxdiff(a, b)
+        print(f"[pin] NMS with labels B={B} N={N} conf={conf} multi_label={ml}: kept {[int(a.shape[0]) for a in ref]} identical")
+        cases.append(dict(B=B, N=N, nc=nc, conf=conf, iou=iou, multi_label=ml, agnostic=False, classes=None, seed=seed,
+                          labels=[l.clone() for l in lab], out=[a.clone() for a in ref], index=[i.clone() for i in idx]))
     torch.save(cases, os.path.join(out, "nms.pt"))
     print("[pin] wrote nms.pt")
 

@@ -435,8 +435,10 @@ def box_iou(box1: Tensor, box2: Tensor) -> Tensor:
 
 
 def non_max_suppression(prediction: Tensor, conf_thres: float = 0.25, iou_thres: float = 0.45, classes=None,
-                        agnostic: bool = False, multi_label: bool = False, nms_fn=None, return_index: bool = False):
-    """general.py:425-512 (labels=() - no autolabelling), with torchvision.ops.nms restated
+                        agnostic: bool = False, multi_label: bool = False, nms_fn=None, return_index: bool = False,
+                        labels=()):
+    """general.py:425-512 incl. the autolabelling rows (:451-458: `labels[xi]` = (nl, 5) [cls, x, y, w, h] appended
+    after the confidence filter as rows with obj = 1 and a one-hot class; their row index is N + k), with torchvision.ops.nms restated
     as greedy_nms (stable descending score order).  The over-max_nms truncation uses a stable
     descending sort where the reference's argsort leaves tie order unspecified.
     return_index: also return, per image, the candidate id  row * nc + class  (row = index into the
@@ -451,6 +453,14 @@ def non_max_suppression(prediction: Tensor, conf_thres: float = 0.25, iou_thres:
     for xi, x in enumerate(prediction):
         rows = xc[xi].nonzero().view(-1)
         x = x[xc[xi]].clone()
+        if labels and len(labels[xi]):
+            l = labels[xi]
+            v = torch.zeros((len(l), nc + 5))
+            v[:, :4] = l[:, 1:5]
+            v[:, 4] = 1.0
+            v[range(len(l)), l[:, 0].long() + 5] = 1.0
+            x = torch.cat((x, v), 0)
+            rows = torch.cat((rows, prediction.shape[1] + torch.arange(len(l))))
         if not x.shape[0]:
             continue
         x[:, 5:] *= x[:, 4:5]

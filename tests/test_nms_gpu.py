@@ -34,8 +34,9 @@ def test_golden_cases(nms, dev):
     for c in cases:
         z = R.synthetic_predictions(c["B"], c["N"], c["nc"], seed=c["seed"])
         out, idx = nms.non_max_suppression(z.to(dev), c["conf"], c["iou"], classes=c["classes"], agnostic=c["agnostic"],
-                                           multi_label=c["multi_label"], return_index=True)
+                                           multi_label=c["multi_label"], return_index=True, labels=c.get("labels", ()))
         _check(out, idx, c["out"], c["index"])
+    assert sum("labels" in c for c in cases) >= 2        # autolabelling rows (general.py:451-458) are pinned too
 
 
 @pytest.mark.parametrize("N,conf,iou,ml", [(196608, 0.001, 0.6, True), (196608, 0.25, 0.45, False), (2500, 0.3, 0.45, True),
@@ -67,5 +68,5 @@ def test_empty_and_errors(nms, dev):
     assert all(o.shape == (0, 6) for o in out)
     with pytest.raises(RuntimeError):
         nms.non_max_suppression(z, 0.25, 0.45)                      # CPU tensor: no fallback
-    with pytest.raises(NotImplementedError):
-        nms.non_max_suppression(z.to(dev), 0.25, 0.45, labels=[torch.zeros(1, 5), torch.zeros(0, 5)])
+    with pytest.raises(ValueError):
+        nms.non_max_suppression(z.to(dev), 0.25, 0.45, labels=[torch.zeros(1, 5)])      # one label tensor per image

@@ -116,11 +116,11 @@ def test_greedy_nms_spec():
 def test_nms_oracle_matches_reference_golden():
     """oracle non_max_suppression vs the outputs of the reference's own function (general.py:425), nms.pt."""
     cases = torch.load(os.path.join(GOLD, "nms.pt"))
-    assert len(cases) >= 6
+    assert len(cases) >= 8 and sum("labels" in c for c in cases) >= 2
     for c in cases:
         z = R.synthetic_predictions(c["B"], c["N"], c["nc"], seed=c["seed"])
         out, idx = R.non_max_suppression(z, c["conf"], c["iou"], classes=c["classes"], agnostic=c["agnostic"],
-                                         multi_label=c["multi_label"], return_index=True)
+                                         multi_label=c["multi_label"], return_index=True, labels=c.get("labels", ()))
         for o, i, ro, ri in zip(out, idx, c["out"], c["index"]):
             assert o.shape == ro.shape
             assert torch.equal(i, ri)
