@@ -40,6 +40,32 @@ class Plan:
         self.bwd_main: Optional[list] = None
         self.saved: dict = {}
 
+    def zbuf(self, pool, name, shape, dtype):
+        """Small accumulator that must be zero at the start of every forward (pool "f") or backward (pool "b"): carved out of
+        one 2 MiB pool per direction that a single memset clears (24 tiny memset launches per step otherwise)."""
+        t = self.bufs.get(name)
+        if t is None:
+            pbuf = self.zpool(pool)
+            n = 1
+            for d in shape:
+                n *= d
+            nbytes = n * torch.empty((), dtype=dtype).element_size()
+            off = self.zused[pool]
+            if off + nbytes > pbuf.numel():
+                raise RuntimeError("zero pool exhausted")
+            t = pbuf[off: off + nbytes].view(dtype).view(shape)
+            self.zused[pool] = (off + nbytes + 255) // 256 * 256
+            self.bufs[name] = t
+        return t
+
+    def zpool(self, pool):
+        pbuf = self.bufs.get("zpool." + pool)
+        if pbuf is None:
+            pbuf = self.bufs["zpool." + pool] = torch.zeros(1 << 21, device=self.dev, dtype=torch.uint8)
+            self.zused = getattr(self, "zused", {})
+            self.zused[pool] = 0
+        return pbuf
+
     def buf(self, name, shape, dtype=None, zero=False):
         t = self.bufs.get(name)
         if t is None:
@@ -437,6 +463,8 @@ class Engine:
         p, w = self.params, P["w"]
         T1 = B * t * t
         x0 = plan.bufs["x0"]
+        if plan.training and not self.fused:
+            ops.zero_(plan.zpool("f"))               # BatchNorm column-statistics accumulators of every head conv
         # 1x1 token-mixing conv + bias + pos_embed (only when t matches: backbone_vit.py:215-217)
         x = plan.buf("xe", (T1, 192))
         use_pos = (t == self.img_t)
@@ -637,9 +665,8 @@ class Engine:
             ops.gemm_nt(segs, w[wname], y, M, Cout, K, spatial=spatial, affine=(ones, p[pname + "conv.bias"]))
         elif plan.training:
             z = plan.buf(tag + ".z", (M, Cout))
-            stats = plan.buf(tag + ".stats", (L.STATS_REPL, 2, Cout), torch.float64)
+            stats = plan.zbuf("f", tag + ".stats", (L.STATS_REPL, 2, Cout), torch.float64)   # zeroed with the pool (_forward_main)
             mr = plan.buf(tag + ".mr", (2, Cout), torch.float32)
-            ops.zero_(stats)
             ops.gemm_nt(segs, w[wname], z, M, Cout, K, spatial=spatial, stats=stats)
             ops.bn_finalize(stats, mr, bufs[pname + "bn.running_mean"], bufs[pname + "bn.running_var"], M, Cout, 1e-3, 0.03)
             ops.bn_silu_fwd(z, mr, p[pname + "bn.weight"], p[pname + "bn.bias"], y, Cout, M, Cout)
@@ -658,9 +685,8 @@ class Engine:
         p, g, b = self.params, self.g, plan.bufs
         sv = plan.saved[tag]
         M, K, Cout, k, pname = sv["M"], sv["K"], sv["Cout"], sv["k"], sv["pname"]
-        red = plan.buf(tag + ".red", (2, Cout), torch.float64)
+        red = plan.zbuf("b", tag + ".red", (2, Cout), torch.float64)                          # zeroed with the pool (_backward_main)
         dz = plan.buf(tag + ".dz", (M, Cout))
-        ops.zero_(red)
         ops.bn_silu_bwd_reduce(dy, lddy, b[tag + ".z"], b[tag + ".mr"], p[pname + "bn.weight"], p[pname + "bn.bias"], red, M, Cout,
                                dy_off=dy_off)
         ops.bn_silu_bwd_apply(dy, lddy, b[tag + ".z"], b[tag + ".mr"], p[pname + "bn.weight"], p[pname + "bn.bias"], red, dz,
@@ -760,6 +786,7 @@ class Engine:
         t = S // 4
         wT, g, b = P["wT"], self.g, plan.bufs
         enc = self.model.image_encoder
+        ops.zero_(plan.zpool("b"))                   # BN-backward reduction accumulators of every head conv
         T1, T2, T3 = B * t * t, B * (t // 2) ** 2, B * (t // 4) ** 2
         h2, h4 = t // 2, t // 4
         # ---- Detect
