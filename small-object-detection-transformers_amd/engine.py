@@ -12,6 +12,8 @@ sequence of HIP kernels (C ABI, include/sodt_hip.h), token-major activations.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, List, Optional, Tuple
 
@@ -26,6 +28,7 @@ E = "image_encoder."
 TAPS2 = ((0, 0), (0, 1), (1, 0), (1, 1))                       # (dy, dx) of the 2x2 conv, kernel index kh*2+kw
 TAPS3 = tuple((dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1))
 MERGE = ((0, 0), (1, 0), (0, 1), (1, 1))                        # PatchMerging gather order (backbone_vit.py:850-853)
+USE_HIPGRAPH = os.environ.get("SODT_HIPGRAPH", "0") == "1"     # opt-in: see Engine._replay
 
 
 class Plan:
@@ -39,6 +42,7 @@ class Plan:
         self.fwd_main: Optional[list] = None
         self.bwd_main: Optional[list] = None
         self.saved: dict = {}
+        self.graphs: dict = {}                    # hipGraph of a recorded list (captured on its first replay)
 
     def zbuf(self, pool, name, shape, dtype):
         """Small accumulator that must be zero at the start of every forward (pool "f") or backward (pool "b"): carved out of
@@ -449,13 +453,33 @@ class Engine:
                 self._forward_main(plan, P)
             plan.fwd_main = rec.calls
         else:
-            ops.replay(plan.fwd_main, probes=self.probes_fwd)
+            self._replay(plan, "fwd_main", plan.fwd_main, self.probes_fwd)
         # (4) Detect: live (fresh output tensor every call)
         T1 = B * t * t
         pred = torch.empty(B, self.na, t, t, self.no, device=self.dev, dtype=torch.float32)
         ops.gemm_nt([SegSpec(plan.bufs["h7.cv3.y"])], P["w"]["detect.8.m.0.weight"], pred, T1, self.na * self.no, 128,
                     bias=self.params["detect.8.m.0.bias"], detect=(self.na, self.no, t * t))
         return pred
+
+    def _replay(self, plan: Plan, key: str, calls, probes):
+        """Re-issue a recorded launch list.  With SODT_HIPGRAPH=1 (single-process runs without probes) the list is captured
+        into a hipGraph on its first replay - every launch goes to the caller's stream and all pointers are plan-owned, so the
+        capture is exact - and the graph is launched from then on: one host call instead of ~350 ctypes calls per list.
+        Off by default: the step is GPU-bound (43 ms of kernels against ~0.5 ms of host replay that runs ahead of the GPU;
+        185.6 vs 185.3 img/s measured), and the data-parallel path replays in segments around its all-reduce buckets."""
+        if probes or not USE_HIPGRAPH or self.ddp is not None:
+            ops.replay(calls, probes=probes)
+            return
+        g = plan.graphs.get(key)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(g, stream=side):
+                ops.replay(calls)
+            torch.cuda.current_stream().wait_stream(side)
+            plan.graphs[key] = g
+        g.replay()
 
     def _forward_main(self, plan: Plan, P):
         B, S = plan.B, plan.S
@@ -761,7 +785,7 @@ class Engine:
                 pos = idx
             ops.replay(plan.bwd_main, probes=self.probes_bwd, start=pos)
         else:
-            ops.replay(plan.bwd_main, probes=self.probes_bwd)
+            self._replay(plan, "bwd_main", plan.bwd_main, self.probes_bwd)
         # (3) front end: live
         fe = P["fe"]
         cb = self.model.image_encoder.chan_block

@@ -44,3 +44,32 @@ def test_loss_falls_with_fused_optimizer_and_ema(dev, dt):
     with torch.no_grad():
         z = ema.ema(x, ir, "RGB+IR")[0]
     assert torch.isfinite(z).all()
+
+
+def test_hipgraph_replay_matches_plain_replay(dev, monkeypatch):
+    """SODT_HIPGRAPH=1: the recorded forward / backward launch lists captured into hipGraphs give the same logits and gradients
+    as the plain replay (three steps each: record, capture + first graph launch, graph launch)."""
+    eng_mod = importlib.import_module(PKG + ".engine")
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 256, 256, generator=g).to(dev)
+    ir = torch.rand(2, 3, 256, 256, generator=g).to(dev)
+    res = {}
+    for use in (False, True):
+        monkeypatch.setattr(eng_mod, "USE_HIPGRAPH", use)
+        model, _ = build(dev, 256)
+        model.compute_dtype = torch.float32
+        model.train()
+        for _ in range(3):
+            for p in model.parameters():
+                p.grad = None
+            pred, _ = model(x, ir, "RGB+IR")
+            pred[0].float().square().mean().backward()
+        torch.cuda.synchronize()
+        eng = model._get_engine()
+        plan = next(iter(eng.plans.values()))
+        assert bool(plan.graphs) == use
+        res[use] = (pred[0].detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-5
+    for k, gv in res[False][1].items():
+        d = float((res[True][1][k] - gv).abs().max())
+        assert d <= 2e-5 * max(1.0, float(gv.abs().max())), (k, d)
