@@ -276,21 +276,38 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
   }
 }
 
+// P V operand of the register-resident P strips: V rows (keys) in strip-pair order (see attn_fwd_mt_kernel)
+template <typename T> __device__ __forceinline__ uint4 fragTp_fwd(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane);
+template <> __device__ __forceinline__ uint4 fragTp_fwd<bf16>(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned char* a = tile + (32 * kbq + 4 * g + q) * rowbytes + (col0 + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  union { s16x4 v; uint2 u; } lo, hi;
+  lo.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  hi.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 16 * rowbytes));
+  return make_uint4(lo.u.x, lo.u.y, hi.u.x, hi.u.y);
+}
+template <> __device__ __forceinline__ uint4 fragTp_fwd<float>(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane) {
+  return fragT<float>(tile, rowbytes, 16 * kbq, col0, lane);
+}
+
 // ---------------------------------------------------------------------------------
 // forward, 8x8 windows (one 64-token tile per window: stages 1 and 2).  Persistent workgroups walk the
 // windows of one head group; the next window's Q/K/V chunks are prefetched into registers.  Scores are
 // computed TRANSPOSED (S^T = K Q^T: keys on accumulator rows, queries on lanes) so that a query's softmax
-// is 16 in-lane values + two cross-group shuffles, and P leaves the accumulators as packed 4-key stores
-// straight into the [q][key] layout the P V product reads.  Bias values (x log2 e) sit in 64 registers.
+// is 16 in-lane values + two cross-group shuffles, and P leaves the accumulators directly as the A operand of O += P V
+// (strip pairs for bf16; V read with the transposing LDS load in the same order): no P tile in LDS.  Bias values
+// (x log2 e) sit in 28 registers (strip differences).  bf16, four heads per workgroup: 61 KB of LDS and <= 256 registers, two
+// workgroups per CU.
 // ---------------------------------------------------------------------------------
 template <typename T, int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
+__global__ __launch_bounds__(NW * 64, (NW == 4 && sizeof(T) == 2) ? 2 : 1) void attn_fwd_fast_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
                                                                T* __restrict__ out, float* __restrict__ lse, const AttnGeo g,
                                                                int nwin_total) {
   using L = Lay<T, HD>;
   constexpr int E = L::E, KPL = L::KPL, NT = NW * 64, CPR = NW * L::DCH, NPF = L::DCH, MK = TT<T>::MMA_K;
+  constexpr int SPK = MK / 16;
   __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE], sK[NW * L::QTILE], sV[NW * L::QTILE];
-  __shared__ __attribute__((aligned(16))) unsigned char sP[NW * L::STILE];
   __shared__ float sL[NW][64];
   __shared__ int sTok[64];
   __shared__ short sRid[64];
@@ -302,23 +319,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
   const float scale2 = rsqrtf((float)HD) * SODT_LOG2E;
   const float* bt = bias_t + (long)head * L2 * L2;
   unsigned char* myQ = sQ + w * L::QTILE; unsigned char* myK = sK + w * L::QTILE;
-  unsigned char* myV = sV + w * L::QTILE; unsigned char* myP = sP + w * L::STILE;
+  unsigned char* myV = sV + w * L::QTILE;
 
-  // bias2[ks][ms][r]: key = ks*16 + 4*fg + r (accumulator row), query = ms*16 + fr (lane)
-  float bias2[4][4][4];
+  // 8x8 windows: a 16-token strip is two window rows, so the table entry of (key, query) depends on the strips only
+  // through ms - ks: 7 x 4 bias registers.  bias7[ms - ks + 3][r]: key = ks*16 + 4*fg + r (accumulator row), query = ms*16 + fr
+  float bias7[7][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
+  for (int d = 0; d < 7; ++d) {
+    const int ks = d < 3 ? 3 - d : 0, ms = ks + d - 3;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int kn = ks * 16 + fg * 4 + r;
-      const int kiy = kn / g.ws, kix = kn - kiy * g.ws;
-#pragma unroll
-      for (int ms = 0; ms < 4; ++ms) {
-        const int qn = ms * 16 + fr;
-        const int qiy = qn / g.ws, qix = qn - qiy * g.ws;
-        bias2[ks][ms][r] = bt[(qiy - kiy + g.ws - 1) * L2 + (qix - kix + g.ws - 1)] * SODT_LOG2E;
-      }
+      const int kn = ks * 16 + fg * 4 + r, qn = ms * 16 + fr;
+      const int kiy = kn / g.ws, kix = kn - kiy * g.ws, qiy = qn / g.ws, qix = qn - qiy * g.ws;
+      bias7[d][r] = bt[(qiy - kiy + g.ws - 1) * L2 + (qix - kix + g.ws - 1)] * SODT_LOG2E;
     }
+  }
 
   // prefetch slots as individual registers (arrays / structs were left in scratch by hipcc, serialising the prefetch)
   uint4 pq0, pq1, pq2, pq3, pk0, pk1, pk2, pk3, pv0, pv1, pv2, pv3;
@@ -378,7 +393,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
           if (kb == 0) s[ks][ms] = mma16z<T>(fk[ks], fq[ms]); else mma16<T>(s[ks][ms], fk[ks], fq[ms]);
         }
     }
-    // ---- softmax over keys for query (ms, fr): 16 in-lane values, then across the four 16-lane groups
+    // V^T-side operands of O += P V (rows = keys in strip-pair order), shared by the four query strips
+    uint4 fb[4 / SPK][HD / 16];
+#pragma unroll
+    for (int kbq = 0; kbq < 4 / SPK; ++kbq)
+#pragma unroll
+      for (int d = 0; d < HD / 16; ++d) fb[kbq][d] = fragTp_fwd<T>(myV, L::QROW, kbq, d * 16, lane);
+    f32x4 o[4][HD / 16];
+    // ---- softmax over keys for query (ms, fr): 16 in-lane values, then across the four 16-lane groups; P leaves the
+    //      accumulators as the A operand of O[ms] += P V (no P tile in LDS)
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) {
       const int qrid = MSK ? (int)sRid[ms * 16 + fr] : 0;
@@ -387,7 +410,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = fmaf(s[ks][ms][r], scale2, bias2[ks][ms][r]);
+          float v = fmaf(s[ks][ms][r], scale2, bias7[ms - ks + 3][r]);
           if constexpr (MSK) { if (qrid != (int)sRid[ks * 16 + fg * 4 + r]) v += -100.0f * SODT_LOG2E; }
           s[ks][ms][r] = v;
           mx = fmaxf(mx, v);
@@ -407,27 +430,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
         if (lse) lse[(long)sTok[qn] * g.heads + head] = mx * (1.0f / SODT_LOG2E) + __logf(sum);
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st4<T>(myP + (ms * 16 + fr) * L::TROW + (ks * 16 + fg * 4) * E, s[ks][ms]);
-    }
-    __syncthreads();
-    // ---- O = P V
-    f32x4 o[4][HD / 16];
+      for (int kbq = 0; kbq < 4 / SPK; ++kbq) {
+        uint4 ap;
+        if constexpr (std::is_same<T, bf16>::value) {
+          ap = make_uint4(pack2bf(s[2 * kbq][ms][0], s[2 * kbq][ms][1]), pack2bf(s[2 * kbq][ms][2], s[2 * kbq][ms][3]),
+                          pack2bf(s[2 * kbq + 1][ms][0], s[2 * kbq + 1][ms][1]), pack2bf(s[2 * kbq + 1][ms][2], s[2 * kbq + 1][ms][3]));
+        } else {
+          ap = make_uint4(__float_as_uint(s[kbq][ms][0]), __float_as_uint(s[kbq][ms][1]), __float_as_uint(s[kbq][ms][2]), __float_as_uint(s[kbq][ms][3]));
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int d = 0; d < HD / 16; ++d) o[i][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < L::KBT; ++kb) {
-      uint4 fb[HD / 16];
-#pragma unroll
-      for (int d = 0; d < HD / 16; ++d) fb[d] = fragT<T>(myV, L::QROW, kb * MK, d * 16, lane);
-#pragma unroll
-      for (int ms = 0; ms < 4; ++ms) {
-        const uint4 fa = frag<T>(myP, L::TROW, ms * 16, kb, 64, lane);
-#pragma unroll
-        for (int d = 0; d < HD / 16; ++d) mma16<T>(o[ms][d], fa, fb[d]);
+        for (int d = 0; d < HD / 16; ++d) {
+          if (kbq == 0) o[ms][d] = mma16z<T>(ap, fb[kbq][d]); else mma16<T>(o[ms][d], ap, fb[kbq][d]);
+        }
       }
     }
+    __syncthreads();                                   // sL (1 / sum of every query) is complete
     // ---- normalise, stage through this head's Q tile, coalesced store
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms)
@@ -457,20 +474,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_fast_kernel(const T* __restr
 // P leaves the accumulators directly as the A operand of O += P V (strip pairs for bf16; V read with the transposing
 // LDS load in the same order).  No P tile in LDS.
 // ---------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ uint4 fragTp_fwd(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane);
-template <> __device__ __forceinline__ uint4 fragTp_fwd<bf16>(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane) {
-  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-  const unsigned char* a = tile + (32 * kbq + 4 * g + q) * rowbytes + (col0 + 4 * p) * 2;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  union { s16x4 v; uint2 u; } lo, hi;
-  lo.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
-  hi.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 16 * rowbytes));
-  return make_uint4(lo.u.x, lo.u.y, hi.u.x, hi.u.y);
-}
-template <> __device__ __forceinline__ uint4 fragTp_fwd<float>(const unsigned char* tile, int rowbytes, int kbq, int col0, int lane) {
-  return fragT<float>(tile, rowbytes, 16 * kbq, col0, lane);
-}
-
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_fwd_mt_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
                                                          T* __restrict__ out, float* __restrict__ lse, const AttnGeo g) {
