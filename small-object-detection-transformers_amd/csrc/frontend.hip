@@ -63,8 +63,11 @@ __global__ __launch_bounds__(256) void frontend_fwd_kernel(const float* __restri
                                                           T* __restrict__ out, const FeGeo g, long ntok) {
   __shared__ float sE[4][64][EP];
   __shared__ __attribute__((aligned(16))) T sO[64 * 192];
+  float (*sP)[64][17] = (float (*)[64][17])sO;     // patches [4][64][17]: dead before the first write of the output tile
+  static_assert(4 * 64 * 17 * 4 <= 64 * 192 * sizeof(T), "patch tile aliases the output tile");
   const int tid = threadIdx.x, lane = tid & 63;
   const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t16 = lane & 15, g4 = lane >> 4;
   const long tok0 = (long)blockIdx.x * 64;
   const long tok = tok0 + lane;
   const bool live = tok < ntok;
@@ -79,11 +82,26 @@ __global__ __launch_bounds__(256) void frontend_fwd_kernel(const float* __restri
   }
   const float* wp = w + p * CE * 16;
   const float* bp = bias + p * CE;
-  for (int j = 0; j < CE; ++j) {
-    float a = bp[j];
+  // E^T[ch][tok] = W[ch][tap] P^T[tap][tok] + bias as 3 x 4 tiles of exact-f32 MFMA 16x16x4 (the scalar-weight FMA loop
+  // waited for one s_load round trip per output channel)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a = fmaf(wp[j * 16 + k], pt[k], a);
-    sE[p][lane][j] = a;
+  for (int k = 0; k < 16; ++k) sP[p][lane][k] = pt[k];
+  wave_sync();
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    float pb[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) pb[kk] = sP[p][16 * n + t16][4 * kk + g4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      f32x4 e;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = bp[16 * s + 4 * g4 + r];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) e = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * s + t16) * 16 + 4 * kk + g4], pb[kk], e, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sE[p][16 * n + t16][16 * s + 4 * g4 + r] = e[r];
+    }
   }
   __syncthreads();
   // pair p: LN(e_q + e_kv)
