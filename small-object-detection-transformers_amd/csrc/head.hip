@@ -279,6 +279,28 @@ __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* _
 // out[r][c] (f32) += sum_b d[b][r][c]   (pos_embed gradient: backbone_vit.py:215-217 backward)
 template <typename T>
 __global__ __launch_bounds__(256) void batch_sum_kernel(const T* __restrict__ d, float* __restrict__ out, int B, long RC) {
+  constexpr int KPL = TT<T>::KPL;
+  if ((RC % KPL) == 0 && ((uintptr_t)d & 15) == 0 && ((uintptr_t)out & 15) == 0) {     // 16-byte chunks (the engine's case)
+    const long nch = RC / KPL;
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
+      float s[KPL];
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) s[j] = 0.f;
+      for (int b = 0; b < B; ++b) {
+        float f[KPL];
+        unpack<T>(*(const uint4*)(d + (long)b * RC + c * KPL), f);
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) s[j] += f[j];
+      }
+#pragma unroll
+      for (int j = 0; j < KPL; j += 4) {
+        float4 o = *(float4*)(out + c * KPL + j);
+        o.x += s[j]; o.y += s[j + 1]; o.z += s[j + 2]; o.w += s[j + 3];
+        *(float4*)(out + c * KPL + j) = o;
+      }
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < RC; i += (long)gridDim.x * 256) {
     float s = 0.f;
     for (int b = 0; b < B; ++b) s += to_f(d[(long)b * RC + i]);
@@ -414,7 +436,7 @@ extern "C" int sodt_cast(const void* src, void* dst, long n, int src_dtype, int 
 
 extern "C" int sodt_batch_sum(const void* d, float* out, int B, long RC, int dtype, sodt_stream_t st) {
   if (!d || !out || B <= 0 || RC <= 0) return SODT_EINVAL;
-  const unsigned gr = nblocks(RC);
+  const unsigned gr = nblocks(RC / 4);
   if (dtype == SODT_BF16) hipLaunchKernelGGL(batch_sum_kernel<bf16>, dim3(gr), dim3(256), 0, (hipStream_t)st, (const bf16*)d, out, B, RC);
   else if (dtype == SODT_F32) hipLaunchKernelGGL(batch_sum_kernel<float>, dim3(gr), dim3(256), 0, (hipStream_t)st, (const float*)d, out, B, RC);
   else return SODT_EINVAL;
