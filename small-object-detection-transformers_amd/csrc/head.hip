@@ -411,7 +411,7 @@ extern "C" int sodt_detect_decode(const float* raw, const float* anchor_grid, fl
 
 extern "C" int sodt_prep_weights(const sodt_prep_desc* table_dev, int n, int max_elems, int dtype, sodt_stream_t st) {
   if (!table_dev || n <= 0 || max_elems <= 0) return SODT_EINVAL;
-  unsigned bx = nblocks(max_elems, 64);
+  unsigned bx = nblocks(max_elems / 4, 512);   // the largest weights (768 x 3072) are 2304 transpose tiles: 64 blocks walked 36 tiles each, one latency chain per tile
   if (dtype == SODT_BF16) hipLaunchKernelGGL(prep_kernel<bf16>, dim3(bx, n), dim3(256), 0, (hipStream_t)st, table_dev, n);
   else if (dtype == SODT_F32) hipLaunchKernelGGL(prep_kernel<float>, dim3(bx, n), dim3(256), 0, (hipStream_t)st, table_dev, n);
   else return SODT_EINVAL;
