@@ -83,7 +83,9 @@ __device__ __forceinline__ long seg3_row(const Seg3& s, bool ok, int b, int y, i
   return ((long)b * s.Hi + yi) * s.Wi + xi;
 }
 
-template <int CF>
+// OSC: the output rows are scattered (PatchMerging backward: row m of the half-resolution grid -> one of the four
+// stride-2 positions of the full grid); only with CF == 0
+template <int CF, bool OSC = false>
 __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -334,7 +336,10 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
             v[4] += __uint_as_float(b1.x); v[5] += __uint_as_float(b1.y); v[6] += __uint_as_float(b1.z); v[7] += __uint_as_float(b1.w);
           }
           constexpr int CF2 = CF & ~(SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_DGELU | SODT_EPI_DGELU_RC);
-          if (m < g.M) epi_chunk<bf16, CF2>(g, CF2, m, n, v, hw);
+          if (m < g.M) {
+            if constexpr (OSC) epi_chunk<bf16, -1>(g, CF2, m, n, v, hw);      // (generic path: knows the row scatter)
+            else epi_chunk<bf16, CF2>(g, CF2, m, n, v, hw);
+          }
           acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -344,11 +349,11 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the dummy tail DMAs must land before the LDS is released
 }
 
-template <int CF>
+template <int CF, bool OSC = false>
 int launch_nt3(const sodt_gemm_args* g, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt3_kernel<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)gemm_nt3_kernel<CF, OSC>, hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS) != hipSuccess) {
       (void)hipGetLastError();
       return SODT_EINVAL;
     }
@@ -356,7 +361,7 @@ int launch_nt3(const sodt_gemm_args* g, hipStream_t st) {
   }
   const long ntiles = (long)((g->M + T3_BM - 1) / T3_BM) * (g->N / T3_BN);
   const int grid = (int)(ntiles < 256 ? ntiles : 256);
-  hipLaunchKernelGGL((gemm_nt3_kernel<CF>), dim3(grid), dim3(512), T3_LDS, st, *g);
+  hipLaunchKernelGGL((gemm_nt3_kernel<CF, OSC>), dim3(grid), dim3(512), T3_LDS, st, *g);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
@@ -731,7 +736,7 @@ bool sodt_nt3_eligible(const sodt_gemm_args* g) {
       break;
     default: return false;
   }
-  if (g->oscatter || g->rmod > 0) return false;
+  if (g->rmod > 0 || (g->oscatter && (g->flags != 0 || !g->a.spatial))) return false;
   if (g->N % T3_BN || g->K % T3_BK || g->K < 192 || g->M < T3_BM) return false;
   if ((g->flags & SODT_EPI_RESID) && (g->ldr % 8)) return false;
   if ((g->flags & SODT_EPI_DGELU) && (g->ldaux % 8)) return false;
@@ -744,7 +749,7 @@ bool sodt_nt3_eligible(const sodt_gemm_args* g) {
 
 int sodt_nt3_launch(const sodt_gemm_args* g, hipStream_t st) {
   switch (g->flags) {
-    case 0: return launch_nt3<0>(g, st);
+    case 0: return g->oscatter ? launch_nt3<0, true>(g, st) : launch_nt3<0>(g, st);
     case SODT_EPI_BIAS: return launch_nt3<SODT_EPI_BIAS>(g, st);
     case SODT_EPI_RESID: return launch_nt3<SODT_EPI_RESID>(g, st);
     case SODT_EPI_BIAS | SODT_EPI_RESID: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_RESID>(g, st);

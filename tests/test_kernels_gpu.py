@@ -213,6 +213,30 @@ def test_gemm_nt_conv_taps(ops, dev, dt, variant):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Cc,H,W", [(192, 32, 32), (384, 16, 32)])
+def test_gemm_nt_patch_merge_scatter_pipelined_sizes(ops, dev, dt, Cc, H, W):
+    """PatchMerging input gradient (4 GEMMs with output-row scatter, backbone_vit.py:850-857 backward) at sizes the
+    pipelined bf16 NT kernel takes (N % 192 == 0, M >= 256): the scatter epilogue of gemm_nt3_kernel<0, OSC>."""
+    B = 2
+    M2 = B * (H // 2) * (W // 2)
+    Wr = rnd((2 * Cc, 4 * Cc), dev, dt, 2, 0.05)
+    dz = rnd((M2, 2 * Cc), dev, dt, 3)
+    WrT = Wr.t().contiguous()                       # [4C][2C]
+    dx = torch.zeros(B * H * W, Cc, device=dev, dtype=dt)
+    for tap, (dy, dxx) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+        ops.gemm_nt([ops.SegSpec(dz, 2 * Cc, 0, 0, 0, 1, 0, H // 2, W // 2)], WrT, dx, M2, Cc, 2 * Cc,
+                    spatial=(H // 2, W // 2), w_off=tap * Cc * 2 * Cc, oscatter=(2, dy, dxx, H, W))
+    full = dz.float() @ Wr.float()                  # [M2][4C]
+    refdx = torch.zeros(B, H, W, Cc, device=dev)
+    f4 = full.view(B, H // 2, W // 2, 4, Cc)
+    refdx[:, 0::2, 0::2] = f4[..., 0, :]
+    refdx[:, 1::2, 0::2] = f4[..., 1, :]
+    refdx[:, 0::2, 1::2] = f4[..., 2, :]
+    refdx[:, 1::2, 1::2] = f4[..., 3, :]
+    close(dx, refdx.view(-1, Cc), dt, what="patch merge dx (pipelined sizes)")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_gemm_nt_merge_upsample_scatter(ops, dev, dt, variant):
     B, H, W, Cc = 2, 8, 12, 64
     x = rnd((B, H, W, Cc), dev, dt, 1)
