@@ -78,7 +78,7 @@ def cpu_baseline(S=1024, iters=3):
     med_s, best_s = run(1, S)
     med_512, best_512 = run(2, 512)
     return {"value": round(med_s, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/ref_torch.py (CPU port of the reference path) fwd+bwd f32, {iters} timed iterations after 1 warm-up: "
+            "sample": f"oracle/ref_torch.py (CPU port of the reference path) fwd+bwd ONLY (loss = mean(pred^2); no ComputeLoss, optimizer or EMA step, unlike `value`), f32, {iters} timed iterations after 1 warm-up: "
                       f"B=1 @{S}x{S} median {med_s:.3f} img/s (best {best_s:.3f}); B=2 @512x512 median {med_512:.3f} img/s "
                       f"(best {best_512:.3f}); torch threads={threads}, os.cpu_count()={n}"}
 

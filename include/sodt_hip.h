@@ -226,7 +226,9 @@ int sodt_gather_sum_rows(const void* d, int ldd, void* dsrc, int lds_, int B, in
 
 /* nn.MaxPool2d(5, stride 1, padding 2), token-major, the unit of SPP (common.py:129-140: its 5 / 9 / 13 pools are this pool
  * applied 1 / 2 / 3 times).  argmax (nullable in inference): one byte per (token, channel), window slot ky*5+kx of the
- * first maximum in scan order (what PyTorch's backward routes to).  bwd: dx (+)= gather of dy through argmax. */
+ * first maximum in scan order of THAT 5x5 window (PyTorch's rule for a 5x5 pool; for the cascaded 9 / 13 pools ties inside
+ * the composed window may resolve to a different, equally valid, tied element than torch's single 9x9 / 13x13 scan).
+ * bwd: dx (+)= gather of dy through argmax. */
 int sodt_maxpool5_fwd(const void* x, int ldx, void* y, int ldy, unsigned char* argmax, int B, int H, int W, int C,
                       int dtype, sodt_stream_t st);
 int sodt_maxpool5_bwd(const void* dy, int lddy, const unsigned char* argmax, void* dx, int lddx, int accumulate,

@@ -383,12 +383,19 @@ def loss_goldens(out):
     m.detect, m.hyp, m.gr = [det], dict(R.LOSS_HYP), 1.0
     cl = LM.ComputeLoss(m)
     cases = []
-    for seed, (B, t, per) in enumerate([(2, 16, 12), (1, 32, 40), (2, 16, 0), (2, 8, 30)]):     # 30 boxes on 8x8: duplicate cells
+    # 30 boxes on 8x8: duplicate cells; last case: targets on / over the right and bottom border (x or y == 1.0): the
+    # reference clamps the cell index IN PLACE before tbox = gxy - gij (loss.py:219-221), so tbox uses the clamped cell
+    for seed, (B, t, per) in enumerate([(2, 16, 12), (1, 32, 40), (2, 16, 0), (2, 8, 30), (2, 16, 10)]):
         torch.manual_seed(100 + seed)
         pred = torch.randn(B, 3, t, t, 13, requires_grad=True)
         tg = R.synthetic_targets(B, per, 8, seed) if per else torch.zeros(0, 6)
         if (B, t) == (2, 8):
             tg[:, 4:6] *= 8.0                                                      # boxes large enough for the 8x8 grid's anchors
+        if seed == 4:
+            tg[:, 4:6] = tg[:, 4:6] * 4.0 + 0.15                                   # wide enough to pass anchor_t on a 16-grid
+            tg[0::3, 2] = 1.0                                                      # x on the right border
+            tg[1::3, 3] = 1.0                                                      # y on the bottom border
+            tg[2, 2:4] = 1.0
         ref = cl([pred], tg)
         ref[0].backward()
         dref = pred.grad.clone()

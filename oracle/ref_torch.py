@@ -577,7 +577,8 @@ def build_targets(pred: Tensor, targets: Tensor, anchors: Tensor, anchor_t: floa
     gij = (gxy - offsets).long()
     gi, gj = gij.T
     a = t[:, 6].long()
-    idx = (b, a, gj.clamp(0, int(gain[3]) - 1), gi.clamp(0, int(gain[2]) - 1))
+    # the reference clamps gj / gi IN PLACE and they are views of gij (loss.py:219), so tbox (:221) sees the clamped cell
+    idx = (b, a, gj.clamp_(0, int(gain[3]) - 1), gi.clamp_(0, int(gain[2]) - 1))
     return c, torch.cat((gxy - gij, gwh), 1), idx, anchors[a]
 
 

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(128) void loss_candidates_kernel(const LossArgs a) 
     bw = dc(4.f * s2 * s2 * aw); bw.d[2] = 8.f * s2 * aw * s2 * (1.f - s2);
     bh = dc(4.f * s3 * s3 * ah); bh.d[3] = 8.f * s3 * ah * s3 * (1.f - s3);
   }
-  const float tx = gx - (float)gix, ty = gy - (float)giy;                                                             // tbox (:221)
+  const float tx = gx - (float)gi, ty = gy - (float)gj;      // tbox (:221) uses the cell index AFTER the in-place clamp of :219
   const float eps = 1e-7f;
   const D4 b1x1 = bx - scl(bw, 0.5f), b1x2 = bx + scl(bw, 0.5f), b1y1 = by - scl(bh, 0.5f), b1y2 = by + scl(bh, 0.5f);
   const D4 b2x1 = dc(tx - gw / 2), b2x2 = dc(tx + gw / 2), b2y1 = dc(ty - gh / 2), b2y2 = dc(ty + gh / 2);

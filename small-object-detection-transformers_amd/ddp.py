@@ -107,6 +107,7 @@ def attach(model, group=None, average: bool = True, broadcast: bool = True):
             dist.broadcast(t.data, src=0, group=group)
     if next(model.parameters()).is_cuda:
         model._get_engine().ddp = red
+        model._get_engine().invalidate_params()     # the broadcast wrote the masters through p.data
     else:
         model._pending_ddp = red
     model.grad_reducer = red

@@ -235,10 +235,23 @@ class Engine:
                 p.data = v
         self.flat_cast: Dict[torch.dtype, torch.Tensor] = {}     # run-dtype mirror of flat_param (bf16 path)
         self.param_cast_fresh = False     # True: flat_cast == cast(flat_param) (set by optim.FusedSGD.step, cleared by invalidate_params)
+        self._cast_version = -1           # params_version() at the moment the mirror was last made fresh
+
+    def params_version(self) -> int:
+        """Sum of the parameters' autograd version counters: every in-place write through the Parameter objects
+        (load_state_dict's copy_, a torch optimizer's add_, p.mul_() under no_grad) bumps it.  Writes through `p.data`
+        aliases and raw kernels do not: those callers use invalidate_params()."""
+        return sum(p._version for p in self.params.values())
+
+    def mark_cast_fresh(self):
+        """optim.FusedSGD.step: the fused kernel has just written cast(flat_param) into the mirror."""
+        self.param_cast_fresh = True
+        self._cast_version = self.params_version()
 
     def invalidate_params(self):
         """Tell the engine the f32 masters were changed by something other than optim.FusedSGD (load_state_dict, a torch
-        optimizer, manual edits): the run-dtype mirror is re-cast at the next forward."""
+        optimizer, manual edits): the run-dtype mirror is re-cast at the next forward.  In-place writes through the
+        Parameter objects are also detected by their version counters (params_version)."""
         self.param_cast_fresh = False
 
     def _check_param_views(self):
@@ -427,8 +440,12 @@ class Engine:
         plan.gen += 1          # the saved activations of an earlier forward on this plan are gone (see _EngineFn.backward)
         # (0) run-dtype mirror of the masters: written by the fused optimizer step; re-cast here when anything else may have
         #     changed them (live call: the decision is per step)
-        if plan.dt != torch.float32 and not self.param_cast_fresh:
-            ops.cast(self.flat_param, self.flat_cast[plan.dt], self.flat_param.numel())
+        if plan.dt != torch.float32:
+            ver = self.params_version()
+            if not self.param_cast_fresh or ver != self._cast_version:
+                ops.cast(self.flat_param, self.flat_cast[plan.dt], self.flat_param.numel())
+                # stays valid until the masters change: fresh only when an optimizer that maintains the mirror is stepping
+                self._cast_version = ver
         # (1) parameter preparation (recorded)
         if plan.fwd_pre is None:
             with ops.Recorder() as rec:

@@ -50,7 +50,12 @@ class _LossFn(torch.autograd.Function):
                     C.c_float(hyp["obj_pw"]), C.c_float(hyp["anchor_t"]), C.c_float(gr), ws.data_ptr(), nbytes.value,
                     dpred.data_ptr(), out.data_ptr())
         ctx.save_for_backward(dpred)
-        return out[0:1], out[1:2], out[2:3], out[3:4]
+        # independent tensors, not slices of `out`: views of one buffer returned by a multi-output Function are
+        # MULTI_OUTPUT_NODE views on which the reference loop's in-place `loss *= opt.world_size` (Train.py:440),
+        # `loss *= 4.` and `loss += sr_loss` raise
+        loss, lbox, lobj, lcls = (out[i:i + 1].clone() for i in range(4))
+        ctx.mark_non_differentiable(lbox, lobj, lcls)
+        return loss, lbox, lobj, lcls
 
     @staticmethod
     def backward(ctx, g_loss, g_box, g_obj, g_cls):

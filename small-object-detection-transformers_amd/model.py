@@ -363,6 +363,12 @@ class Model(nn.Module):
         self.materialize_features = False
         self._engine = None
         self._nms: Optional[NMS] = None      # set by .nms(); kept outside self.model so state_dict keys do not move
+        # load_state_dict (resume, best weights) rewrites the f32 masters: the engine's run-dtype mirror must be re-cast
+        self.register_load_state_dict_post_hook(lambda module, keys: module._invalidate_engine_params())
+
+    def _invalidate_engine_params(self):
+        if getattr(self, "_engine", None) is not None:
+            self._engine.invalidate_params()
 
     # ------------------------------------------------------------------ reference helpers
     def _initialize_biases(self, cf=None):      # model.py:299-307
@@ -405,7 +411,8 @@ class Model(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k == "_engine" else deepcopy(v, memo)
+            # the engine and the data-parallel reducer (ddp.attach: process-group handles) belong to the training model only
+            new.__dict__[k] = None if k in ("_engine", "grad_reducer", "_pending_ddp") else deepcopy(v, memo)
         return new
 
     def __getstate__(self):                     # checkpoints pickle the module object (Train.py:531-532)

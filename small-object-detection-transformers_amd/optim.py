@@ -128,13 +128,20 @@ class FusedSGD(torch.optim.Optimizer):
             raise ValueError("FusedSGD: nesterov must be the same for every group")
         ema_flat, d = None, 0.0
         if self.ema is not None:
+            ema_eng = self.ema.ema._get_engine()
+            if self.ema.flat is not ema_eng.flat_param:       # the EMA model's engine was rebuilt (fuse(), unpickled / assigned model)
+                self.ema.flat = ema_eng.flat_param
+            ema_eng._check_param_views()
             ema_flat, d = self.ema.flat, self.ema.next_decay()
             self.ema._fused_pending = True
         cast = next(iter(eng.flat_cast.values())) if eng.flat_cast else None
         ops.sgd_ema_step(eng.flat_param, eng.flat_grad, self._mom, ema_flat, cast, self._groups,
                          [g["lr"] for g in gs], [g["momentum"] for g in gs], [g["weight_decay"] for g in gs],
                          nest.pop(), grad_scale, d)
-        eng.param_cast_fresh = cast is not None
+        if cast is not None:
+            eng.mark_cast_fresh()
+        else:
+            eng.param_cast_fresh = False
         return loss
 
     def state_dict(self):
@@ -143,6 +150,7 @@ class FusedSGD(torch.optim.Optimizer):
         return sd
 
     def load_state_dict(self, sd):
+        sd = dict(sd)                       # the caller's dict keeps its "momentum_flat" entry
         mom = sd.pop("momentum_flat", None)
         super().load_state_dict(sd)
         if mom is not None:

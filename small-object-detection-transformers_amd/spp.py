@@ -6,6 +6,12 @@ concat never exists: cv2 reads [a1 | m5 | m9 | m13] as four K-segments of one GE
 as one [M][4 c_] tensor whose slices the pool backward accumulates through in place.  BatchNorm is the batch-statistics
 form of the head's Conv (f64 column sums in the GEMM epilogue, engine.Engine._conv_fwd).
 
+Ties: forward values equal nn.MaxPool2d(9 / 13) exactly.  The backward routes each gradient through the chain of per-stage
+first-in-scan-order argmax positions of the 5x5 pools; when the 9x9 / 13x13 window holds several equal maxima this can
+pick a different (equally valid) subgradient than torch's single-window first-in-row-major choice.  With distinct
+maxima (the tested case, tests/golden/spp.pt) the two agree; a map with exact ties (constant regions, coarse bf16
+quantisation after SiLU) gets the same total gradient mass per window placed on another tied element.
+
 model.yaml's head has no SPP (it appears in the SuperYOLO CNN configs this fork can no longer parse, SURVEY.md appendix
 C), so the engine's fixed graph does not call this; ``SPP`` in model.py holds the parameters with the reference's names
 and this module is the operator a graph with an SPP row would use.

@@ -54,3 +54,20 @@ def test_compute_loss_vs_oracle(dev, B, t, per, scale):
     assert float((pg.grad.cpu() - pr.grad).abs().max()) <= 2e-6 + 3e-5 * float(pr.grad.abs().max())
     n = R.build_targets(pred, tg, anchors)[2][0].shape[0]
     assert n > 0
+
+
+def test_reference_loop_inplace_ops_on_loss(dev):
+    """Train.py:440 (`loss *= opt.world_size`), :427 (`loss += sr_loss`): the four outputs must be independent tensors, not
+    views of one multi-output buffer."""
+    Lm = importlib.import_module(PKG + ".loss")
+    c = torch.load(os.path.join(GOLD, "loss.pt"))[0]
+    cl = Lm.ComputeLoss(_fake_model(c["anchors"], c["hyp"], c["gr"], dev))
+    pred = c["pred"].to(dev).requires_grad_(True)
+    loss, lbox, lobj, lcls = cl([pred], c["targets"].to(dev))
+    loss *= 2
+    loss += 0.5 * lbox.detach()
+    loss.backward()
+    torch.cuda.synchronize()
+    err = float((pred.grad.cpu() - 2.0 * c["dpred"]).abs().max())
+    assert err <= 4e-6 + 4e-5 * float(c["dpred"].abs().max())
+    assert not lbox.requires_grad and not lobj.requires_grad and not lcls.requires_grad

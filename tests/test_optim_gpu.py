@@ -111,3 +111,44 @@ def test_fused_sgd_skips_without_gradients_and_checks_views(dev):
     assert torch.equal(before, m._get_engine().flat_param)
     sd = opt.state_dict()
     opt.load_state_dict(sd)
+
+
+def test_bf16_mirror_follows_load_state_dict_after_fused_step(dev):
+    """after a fused step the bf16 mirror is marked fresh; load_state_dict (resume / best weights), a torch
+    optimizer or any in-place write through the Parameter objects must make the next forward re-cast it."""
+    O = importlib.import_module(PKG + ".optim")
+    m, ref = _build(dev), _build(dev)
+    m.compute_dtype = ref.compute_dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(7)
+    x, ir = torch.rand(1, 3, 128, 128, generator=g).to(dev), torch.rand(1, 3, 128, 128, generator=g).to(dev)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    opt = O.FusedSGD(O.set_weight_decay(m), model=m, lr=0.5)
+    m(x, ir, "RGB+IR")[0][0].square().mean().backward()
+    opt.step()                                           # masters AND mirror move away from sd0; mirror marked fresh
+    eng = m._get_engine()
+    assert eng.param_cast_fresh
+    m.load_state_dict(sd0)                               # back to the start through Parameter.copy_
+    ref.load_state_dict(sd0)
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        a = m(x, ir, "RGB+IR")[1][0]
+        b = ref(x, ir, "RGB+IR")[1][0]
+    assert torch.equal(a, b), float((a - b).abs().max())
+    assert torch.equal(eng.flat_cast[torch.bfloat16], eng.flat_param.to(torch.bfloat16))
+    # an in-place edit through the Parameter (a torch optimizer's add_) is detected by the version counters
+    m.train()
+    m(x, ir, "RGB+IR")[0][0].square().mean().backward()
+    opt.step()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.01)
+    m.eval()
+    with torch.no_grad():
+        m(x, ir, "RGB+IR")
+    assert torch.equal(eng.flat_cast[torch.bfloat16], eng.flat_param.to(torch.bfloat16))
+    # deep copies (ModelEMA) do not carry the reducer of ddp.attach
+    m.grad_reducer = object()
+    assert copy.deepcopy(m).grad_reducer is None
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    assert "momentum_flat" in sd
