@@ -363,12 +363,13 @@ class Model(nn.Module):
         self.materialize_features = False
         self._engine = None
         self._nms: Optional[NMS] = None      # set by .nms(); kept outside self.model so state_dict keys do not move
-        # load_state_dict (resume, best weights) rewrites the f32 masters: the engine's run-dtype mirror must be re-cast
-        self.register_load_state_dict_post_hook(lambda module, keys: module._invalidate_engine_params())
 
-    def _invalidate_engine_params(self):
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        # resume / best weights rewrite the f32 masters: the engine's run-dtype mirror must be re-cast at the next forward
+        res = super().load_state_dict(state_dict, *args, **kwargs)
         if getattr(self, "_engine", None) is not None:
             self._engine.invalidate_params()
+        return res
 
     # ------------------------------------------------------------------ reference helpers
     def _initialize_biases(self, cf=None):      # model.py:299-307
