@@ -1,0 +1,479 @@
+// Fused W-MSA / SW-MSA half of a Swin block for gfx950, bf16 throughput path: FOUR WAVES PER WINDOW.
+//
+//     x_mid = x + Proj( WindowAttention( LN1(x) ) )          backbone_vit.py:1088-1126, :961-992
+//     xn2   = LN2(x_mid)                                     backbone_vit.py:1128 (the MLP's input)
+//
+// Same contract, parameter pack and saved-tensor layouts as wmsa_block.hip (which stays the f32 parity path); what
+// changes is the work decomposition.  wmsa_block.hip gives one wave a whole window: a 24 KB LN1 tile per wave caps the
+// workgroup at four waves = ONE wave per SIMD with a 512-register budget, so MFMA, softmax VALU and memory phases of a
+// window run back to back and a lone wave issues one VALU instruction per 4 cycles.  Here a workgroup is EIGHT waves
+// (two per SIMD, <= 256 registers each) working on TWO windows:
+//
+//   * the four waves of a window share its LN1 tile in LDS ([64][192] bf16, XOR-swizzled 16-byte chunks) and split the
+//     HEADS: at step i = 0, 1, 2 wave j owns head 4 i + j end to end (q^T, k^T, v by MFMA from the shared tile, S^T = K Q^T,
+//     relative-position bias from the strip-difference table, -100 shift mask, softmax in registers, O^T = V^T P^T) - the
+//     operand chaining of wmsa_block.hip unchanged, nothing of a head ever leaves the wave's registers;
+//   * token-major phases (LN1 prologue, residual + LN2 epilogue) split the TOKENS: wave j owns rows 16 j .. 16 j + 15;
+//   * the output projection splits the OUTPUT CHANNELS: O^T of the 12 heads meets in the (dead) LN1 tile, wave j computes
+//     out^T rows 48 j .. 48 j + 47 against it with the same three-fragment k-loop as the QKV phase, and the result goes
+//     back through the tile for the token-major epilogue;
+//   * weights: the Wq / Wk / Wv fragments of the four heads of a step (72 KB) sit in ONE LDS buffer shared by both
+//     windows, refilled by LDS-DMA (global_load_lds_dwordx4) right after the step's QKV phase - the softmax / PV part of
+//     the step hides the copy; Wproj (72 KB, natural k order) goes through the same buffer.  Relative-position tables
+//     and q/k/v biases of all 12 heads (26 KB) stay resident.
+//   * ~9 workgroup barriers per window pair; every global store drains in the background (counted vmcnt).
+//
+// LDS: 2 x 24 KB tiles + 72 KB weights + 25.5 KB tables + 3.75 KB vectors (+ 8 KB v patches when saving) = 157.25 KB.
+#include "wmsa_common.h"
+
+namespace {
+
+constexpr int HG_TILE = 64 * 384;                       // one window's [64][192] bf16 tile
+constexpr int HG_WBUF_OFF = 2 * HG_TILE;                // 49152
+constexpr int HG_HEADW = 18432;                         // Wq | Wk | Wv fragments of one head (3 x 6 KB) = 3 Wproj strips
+constexpr int HG_WBUF = 4 * HG_HEADW;                   // 73728
+constexpr int HG_TAB_OFF = HG_WBUF_OFF + HG_WBUF;       // 122880
+constexpr int HG_TABH = 1920 + 256;                     // table (4 shifted copies) + q/k/v bias of one head
+constexpr int HG_LNV_OFF = HG_TAB_OFF + WHEADS * HG_TABH;   // 148992: bproj | g1 | b1 | g2 | b2 (f32)
+constexpr int HG_VP_OFF = HG_LNV_OFF + 5 * WC * 4;      // 152832: per-wave 1 KB v transposition patch (SAVE)
+constexpr int HG_LDS_INF = HG_VP_OFF, HG_LDS_SAVE = HG_VP_OFF + 8 * 1024;
+static_assert(HG_LDS_SAVE <= 160 * 1024, "LDS budget");
+static_assert(WL<bf16>::STAGE == 24576 && WL<bf16>::BIAS_OFF == HG_HEADW && WL<bf16>::BQKV_OFF == HG_HEADW + 1920, "pack layout");
+
+template <bool SAVE>
+__global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
+  typedef bf16 T;
+  using L = WL<bf16>;
+  constexpr int E = 2, KPL = 8, ROWB = 384;
+  typedef uint2 k16_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* const sm3 = (lds_u8*)smem;
+  const unsigned smem0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), ww = w >> 2, j = w & 3;
+  const int t = lane & 15, g = lane >> 4;
+  const unsigned tile = (unsigned)(ww * HG_TILE);
+  // fragment addressing into the window's tile (see wmsa_block.hip: chunk c of row r sits at c ^ (r & 7))
+  const unsigned gx3 = (unsigned)((g ^ (t & 3)) << 4), swb = (unsigned)(((t >> 2) & 1) * 64);
+  const unsigned xrow = tile + (unsigned)(t * ROWB) + gx3;
+  const unsigned xfE = smem0 + xrow + swb, xfO = smem0 + xrow - swb;
+  const unsigned wb16 = smem0 + HG_WBUF_OFF + (unsigned)(j * HG_HEADW) + (unsigned)(lane * 16);
+  const float scale2 = 0.25f * WMSA_LOG2E;
+  // bias-table addressing of this lane (wmsa_block.hip): four consecutive entries at one aligned address, strip difference 0
+  const int j0 = 7 - (t & 7) + 4 * (g & 1), jv = j0 & 3;
+  const int bias_lane_off = (((jv * 15 + (t >> 3) - (g >> 1) + 7) * 16) + (j0 - jv)) * E;
+
+  // ---- weights: LDS-DMA of 72 one-KB pieces, nine per wave.  stage 0..2: Wq|Wk|Wv fragments of heads 4 s .. 4 s + 3 (the
+  // first 18 KB of their pack stages), stage 3: Wproj in natural k order
+  auto dma_w = [&](int stage) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int p = w + 8 * q;
+      const unsigned char* gsrc = stage < 3 ? a.wpk + (size_t)(4 * stage + p / 18) * L::STAGE + (size_t)(p % 18) * 1024
+                                            : a.wpk + L::PROJ2_OFF + (size_t)p * 1024;
+      const unsigned ldst = smem0 + HG_WBUF_OFF + (unsigned)(p * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :: "v"((unsigned)(lane * 16)), "s"(gsrc), "s"(ldst) : "memory", "m0");
+    }
+  };
+#define HG_VMWAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+  dma_w(0);
+  // resident: tables + q/k/v bias of the 12 heads, projection bias, LayerNorm vectors
+  for (int i = tid; i < WHEADS * (HG_TABH / 16); i += 512) {
+    const int h = i / (HG_TABH / 16), c = i % (HG_TABH / 16);
+    ((uint4*)(smem + HG_TAB_OFF + h * HG_TABH))[c] = ((const uint4*)(a.wpk + (size_t)h * L::STAGE + L::BIAS_OFF))[c];
+  }
+  for (int i = tid; i < 5 * WC / 4; i += 512) ((float4*)(smem + HG_LNV_OFF))[i] = ((const float4*)(a.wpk + L::TAIL_OFF))[i];
+
+  const int npairs = (a.nwin + 1) / 2;
+  // token-major phases: this lane's row (token 16 j + t of the window) and its six chunks 4 i + g
+  auto row_of = [&](int pair) {
+    int item = 2 * pair + ww;
+    if (item >= a.nwin) item = a.nwin - 1;
+    const int wx_ = item % a.nwx; item /= a.nwx;
+    const int wy_ = item % a.nwy; const int b_ = item / a.nwy;
+    return (unsigned)wtoken(a, b_, wy_, wx_, 16 * j + t);
+  };
+  uint4 xc[6];
+  if ((int)blockIdx.x < npairs) {
+    const unsigned ro = row_of(blockIdx.x) * (unsigned)ROWB + (unsigned)(g * 16);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xc[i] = *(const uint4*)(a.x + (ro + 64u * i));
+  }
+  // LDS row of this lane in the token-major phases
+  const unsigned trow = tile + (unsigned)((16 * j + t) * ROWB);
+  lds_u8* const p_rE = sm3 + trow + gx3 + swb;           // chunk 4 i + g: even i at +64 b, odd i at -64 b (+ 64 i)
+  lds_u8* const p_rO = sm3 + trow + gx3 - swb;
+  lds_u8* const p_ln = sm3 + HG_LNV_OFF + g * KPL * 4;   // this lane's first channel inside a 4-chunk group
+  __syncthreads();
+
+  for (int it = blockIdx.x; it < npairs; it += gridDim.x) {
+    int item = 2 * it + ww;
+    const bool valid = item < a.nwin;
+    if (!valid) item = a.nwin - 1;
+    int tq = item;
+    const int wx = tq % a.nwx; tq /= a.nwx;
+    const int wy = tq % a.nwy; const int b = tq / a.nwy;
+    const bool msk = a.shift > 0 && (wy == a.nwy - 1 || wx == a.nwx - 1);
+    const unsigned whoff = (unsigned)item * WHEADS;
+    const unsigned myrow = (unsigned)wtoken(a, b, wy, wx, 16 * j + t);
+    const unsigned myoff = myrow * (unsigned)ROWB + (unsigned)(g * 16);
+    unsigned diffm[4] = {0u, 0u, 0u, 0u};
+    if (msk) {
+      int kr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) kr[i] = wrid(a, wy, wx, 16 * (i >> 2) + 4 * g + (i & 3));
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        const int qr = wrid(a, wy, wx, 16 * ms + t);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) diffm[ms] |= (qr != kr[i] ? 1u : 0u) << i;
+      }
+    }
+
+    // ================= prologue: LN1 of this wave's 16 tokens -> tile rows 16 j .. 16 j + 15
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float f[KPL];
+        unpack<T>(xc[i], f);
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) s += f[k];
+      }
+      s = rows_sum(s);
+      const float mu = s * (1.0f / WC);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float f[KPL];
+        unpack<T>(xc[i], f);
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) { const float d = f[k] - mu; q = fmaf(d, d, q); }
+      }
+      q = rows_sum(q);
+      const float rstd = rsqrtf(q * (1.0f / WC) + 1e-5f);
+      if (SAVE && valid && g == 0) *(float2*)((unsigned char*)a.st1 + myrow * 8u) = make_float2(mu, rstd);
+      wave_sync();                                       // this wave's epilogue reads of the same rows are done
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float ga[KPL], be[KPL], f[KPL];
+#pragma unroll
+        for (int k = 0; k < KPL; k += 4) {
+          *(f32x4*)(ga + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (WC + 4 * i * KPL + k) * 4);
+          *(f32x4*)(be + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (2 * WC + 4 * i * KPL + k) * 4);
+        }
+        unpack<T>(xc[i], f);
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) f[k] = fmaf((f[k] - mu) * rstd, ga[k], be[k]);
+        const uint4 y = pack<T>(f);
+        *(__attribute__((address_space(3))) u32x4_*)(((i & 1) ? p_rO : p_rE) + 64 * i) = u32x4_{y.x, y.y, y.z, y.w};
+        if (SAVE && valid) *(uint4*)(a.xn1 + (myoff + 64u * i)) = y;
+      }
+    }
+    // W(0) was requested before the previous pair's epilogue stores (or at kernel start): everything older than the
+    // youngest stores has landed.  The stores themselves stay in flight.
+    if (SAVE) HG_VMWAIT(0); else HG_VMWAIT(12);
+    __syncthreads();                                     // B1: tiles complete, W(0) visible
+
+    k16_t poall[3][4];
+    static_for<0, 3>([&](auto i_) {
+      constexpr int step = decltype(i_)::value;
+      const int h = 4 * step + j;
+      const unsigned tb = smem0 + HG_TAB_OFF + (unsigned)(h * HG_TABH);
+      const unsigned bb3 = tb + (unsigned)bias_lane_off - (unsigned)(3 * 2 * 16 * E);
+      const unsigned sbg = tb + 1920u + (unsigned)(16 * g), sbt = tb + 1920u + (unsigned)(4 * t);
+      typedef typename KR<T>::type kreg_t;
+      // ---- q^T, k^T (channel rows, token columns) and v (token rows, channel columns) of head h
+      u32x4_ bqr = lds_rd128a<0>(sbg), bkr = lds_rd128a<64>(sbg);
+      unsigned bvr = lds_rd32a<128>(sbt);
+      kreg_t biar[7];
+      static_for<0, 7>([&](auto d_) { constexpr int d = decltype(d_)::value; biar[d] = KR<T>::template rd<d * 2 * 16 * E>(bb3); });
+      u32x4_ wf[2][3], xf[2][4];
+      auto issue_k = [&](auto kk_) {
+        constexpr int kk = decltype(kk_)::value, bsel = kk & 1;
+        wf[bsel][0] = lds_rd128a<0 + kk * 1024>(wb16);
+        wf[bsel][1] = lds_rd128a<6144 + kk * 1024>(wb16);
+        wf[bsel][2] = lds_rd128a<12288 + kk * 1024>(wb16);
+        static_for<0, 4>([&](auto ms_) {
+          constexpr int ms = decltype(ms_)::value;
+          xf[bsel][ms] = lds_rd128a<ms * 16 * ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
+        });
+      };
+      issue_k(std::integral_constant<int, 0>{});
+      k16_t pq[4], pqs[4], pkk[4], pv[4];
+      f32x4 qT[4], kT[4], vv[4];
+      static_for<0, 6>([&](auto kk_) {
+        constexpr int kk = decltype(kk_)::value, bsel = kk & 1;
+        if constexpr (kk + 1 < 6) {
+          issue_k(std::integral_constant<int, kk + 1>{});
+          LDS_WAIT(7);
+        } else {
+          LDS_WAIT(0);
+        }
+        LDS_DEP(wf[bsel][0]); LDS_DEP(wf[bsel][1]); LDS_DEP(wf[bsel][2]);
+        LDS_DEP(xf[bsel][0]); LDS_DEP(xf[bsel][1]); LDS_DEP(xf[bsel][2]); LDS_DEP(xf[bsel][3]);
+        if constexpr (kk == 0) {
+          LDS_DEP(bqr); LDS_DEP(bkr); LDS_DEP(bvr);
+          const f32x4 bqv = KR<float>::f4(bqr), bkv = KR<float>::f4(bkr);
+          const float bvs = __uint_as_float(bvr);
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) { qT[ms] = bqv; kT[ms] = bkv; vv[ms] = f32x4{bvs, bvs, bvs, bvs}; }
+        }
+        const uint4 wq = u4(wf[bsel][0]), wk = u4(wf[bsel][1]), wv = u4(wf[bsel][2]);
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          const uint4 x4 = u4(xf[bsel][ms]);
+          mma16<T>(qT[ms], wq, x4);
+          mma16<T>(kT[ms], wk, x4);
+          mma16<T>(vv[ms], x4, wv);
+        }
+      });
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        if (SAVE) pq[ms] = pk16<T>(qT[ms]);
+        pqs[ms] = pk16<T>(qT[ms] * scale2);              // hd^-1/2 x log2 e folded into q: S^T leaves the MFMA ready for exp2
+        pkk[ms] = pk16<T>(kT[ms]); pv[ms] = pk16<T>(vv[ms]);
+      }
+      __syncthreads();                                   // B2/4/6: everyone is done with the weight buffer (step 2: and the LN1 tile)
+      dma_w(step + 1);                                   // next heads' weights / Wproj land under the softmax
+      if constexpr (step == 2) {
+        // x of the NEXT window pair: requested now, consumed by the next prologue
+        const int nx = it + (int)gridDim.x < npairs ? it + (int)gridDim.x : it;
+        const unsigned ro = row_of(nx) * (unsigned)ROWB + (unsigned)(g * 16);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xc[i] = *(const uint4*)(a.x + (ro + 64u * i));
+      }
+      if (SAVE && valid) {
+        unsigned char* qb = a.qkvw + (size_t)(whoff + h) * (3 * 64 * WHD * E);     // uniform
+        const unsigned lo = (unsigned)(t * (WHD * E) + g * 8);
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          *(k16_t*)(qb + (lo + (unsigned)(16 * ms * WHD * E))) = pq[ms];
+          *(k16_t*)(qb + (lo + (unsigned)(64 * WHD * E + 16 * ms * WHD * E))) = pkk[ms];
+        }
+        // v -> [token][16] through a 1 KB per-wave patch, two token strips at a time (the accumulator holds four tokens of
+        // ONE channel per lane)
+        lds_u8* const vp = sm3 + HG_VP_OFF + w * 1024;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          wave_sync();
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *(__attribute__((address_space(3))) T*)(vp + ((16 * m2 + 4 * g + r) * WHD + t) * E) = from_f<T>(vv[2 * half + m2][r]);
+          wave_sync();
+          *(uint4*)(qb + (unsigned)(2 * 64 * WHD * E + half * 1024 + lane * 16)) =
+              u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)(vp + lane * 16));
+        }
+      }
+
+      auto body = [&](auto MSK_) {
+        constexpr bool MSK = decltype(MSK_)::value;
+        // ---- S^T = K Q^T: row = key 16 ks + 4 g + r, column = query 16 ms + t; the bias is the accumulator's initial value
+        f32x4 bia[7];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) { LDS_DEP(biar[d]); bia[d] = KR<T>::f4(biar[d]); }
+        k16_t pp[4][4];                                  // P^T strips, packed: [ks][ms]
+        float inv[4];
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          f32x4 s[4];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) { s[ks] = bia[ms - ks + 3]; mmak16(s[ks], pkk[ks], pqs[ms]); }
+          float mx = -1e30f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if constexpr (MSK) { if ((diffm[ms] >> (4 * ks + r)) & 1u) s[ks][r] += -100.0f * WMSA_LOG2E; }
+              mx = fmaxf(mx, s[ks][r]);
+            }
+          mx = rows_max(mx);
+          float sum = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(s[ks][r] - mx); s[ks][r] = p; sum += p; }
+            pp[ks][ms] = pk16<T>(s[ks]);
+          }
+          sum = rows_sum(sum);
+          inv[ms] = __builtin_amdgcn_rcpf(sum);
+          if (SAVE && valid && g == 0)
+            (a.lsew + (size_t)(whoff + h) * 64)[16 * ms + t] = mx * (1.0f / WMSA_LOG2E) + __logf(sum);
+        }
+        // ---- O^T = V^T P^T: row = channel 4 g + r, column = query
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kp = 0; kp < 2; ++kp)
+            mma16<bf16>(o, make_uint4(pv[2 * kp].x, pv[2 * kp].y, pv[2 * kp + 1].x, pv[2 * kp + 1].y),
+                        make_uint4(pp[2 * kp][ms].x, pp[2 * kp][ms].y, pp[2 * kp + 1][ms].x, pp[2 * kp + 1][ms].y));
+          o *= inv[ms];
+          poall[step][ms] = pk16<T>(o);
+        }
+      };
+      if (msk) body(std::true_type{}); else body(std::false_type{});
+
+      if constexpr (step < 2) {
+        HG_VMWAIT(0);                                    // this wave's pieces of the next weights have landed
+        __syncthreads();                                 // B3/5
+      }
+    });
+
+    // ================= O^T of this wave's three heads -> the (dead) LN1 tile, now the attention-output tile [64][192]
+    // (every wave passed B6 after its last QKV phase: nobody reads LN1 rows any more)
+#pragma unroll
+    for (int step = 0; step < 3; ++step) {
+      const int h = 4 * step + j;
+      const int cw = 2 * h + (g >> 1);
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms)
+        *(__attribute__((address_space(3))) u32x2_*)(sm3 + tile + (16 * ms + t) * ROWB + ((cw ^ (t & 7)) << 4) + 8 * (g & 1)) =
+            u32x2_{poall[step][ms].x, poall[step][ms].y};
+    }
+    HG_VMWAIT(6);                                        // Wproj has landed (the six x loads of the next pair were issued after it)
+    __syncthreads();                                     // B7: attention-output tiles complete, Wproj visible
+
+    if (SAVE && valid) {                                 // attention output, natural token order (operand of the dWproj GEMM)
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        *(uint4*)(a.ao + (myoff + 64u * i)) = u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)(((i & 1) ? p_rO : p_rE) + 64 * i));
+    }
+    // ================= output projection: out^T rows 48 j .. 48 j + 47 (three 16-row strips) x 64 tokens, K = 192
+    f32x4 oT[3][4];
+    {
+      u32x4_ wf[2][3], xf[2][4];
+      auto issue_k = [&](auto kk_) {
+        constexpr int kk = decltype(kk_)::value, bsel = kk & 1;
+        wf[bsel][0] = lds_rd128a<0 + kk * 1024>(wb16);
+        wf[bsel][1] = lds_rd128a<6144 + kk * 1024>(wb16);
+        wf[bsel][2] = lds_rd128a<12288 + kk * 1024>(wb16);
+        static_for<0, 4>([&](auto ms_) {
+          constexpr int ms = decltype(ms_)::value;
+          xf[bsel][ms] = lds_rd128a<ms * 16 * ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
+        });
+      };
+      // projection bias of this lane's channels 16 (3 j + nl) + 4 g .. + 3: the accumulators' initial value
+      const unsigned pbb = smem0 + HG_LNV_OFF + (unsigned)((48 * j + 4 * g) * 4);
+      u32x4_ pbr[3];
+      pbr[0] = lds_rd128a<0>(pbb); pbr[1] = lds_rd128a<64>(pbb); pbr[2] = lds_rd128a<128>(pbb);
+      issue_k(std::integral_constant<int, 0>{});
+      static_for<0, 6>([&](auto kk_) {
+        constexpr int kk = decltype(kk_)::value, bsel = kk & 1;
+        if constexpr (kk + 1 < 6) {
+          issue_k(std::integral_constant<int, kk + 1>{});
+          LDS_WAIT(7);
+        } else {
+          LDS_WAIT(0);
+        }
+        LDS_DEP(wf[bsel][0]); LDS_DEP(wf[bsel][1]); LDS_DEP(wf[bsel][2]);
+        LDS_DEP(xf[bsel][0]); LDS_DEP(xf[bsel][1]); LDS_DEP(xf[bsel][2]); LDS_DEP(xf[bsel][3]);
+        if constexpr (kk == 0) {
+          LDS_DEP(pbr[0]); LDS_DEP(pbr[1]); LDS_DEP(pbr[2]);
+#pragma unroll
+          for (int nl = 0; nl < 3; ++nl)
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms) oT[nl][ms] = KR<float>::f4(pbr[nl]);
+        }
+#pragma unroll
+        for (int nl = 0; nl < 3; ++nl) {
+          const uint4 wa = u4(wf[bsel][nl]);
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) mma16<T>(oT[nl][ms], wa, u4(xf[bsel][ms]));
+        }
+      });
+    }
+    __syncthreads();                                     // B8: everyone is done with the attention-output tile and Wproj
+
+    // residual x of this wave's 16 tokens, then the first weights of the next pair: both before the output stores
+    uint4 xr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xr[i] = *(const uint4*)(a.x + (myoff + 64u * i));
+    dma_w(0);
+    // out^T (+ bias) -> tile, run dtype: the rounding a separate projection launch applies to its output
+#pragma unroll
+    for (int nl = 0; nl < 3; ++nl) {
+      const int cw = 2 * (3 * j + nl) + (g >> 1);
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        const k16_t v = pk16<T>(oT[nl][ms]);
+        *(__attribute__((address_space(3))) u32x2_*)(sm3 + tile + (16 * ms + t) * ROWB + ((cw ^ (t & 7)) << 4) + 8 * (g & 1)) = u32x2_{v.x, v.y};
+      }
+    }
+    __syncthreads();                                     // B9: output tiles complete
+
+    // ================= epilogue: x_mid = x + (out + bproj), xn2 = LN2(x_mid) for this wave's 16 tokens
+    {
+      float v[6][KPL];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float f[KPL], o[KPL];
+        unpack<T>(xr[i], f);
+        unpack<T>(u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)(((i & 1) ? p_rO : p_rE) + 64 * i)), o);
+        // x_mid is stored in bf16: LN2 normalises the ROUNDED value, as a separate LayerNorm launch reading x_mid would
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) { v[i][k] = to_f(from_f<T>(f[k] + o[k])); s += v[i][k]; }
+      }
+      s = rows_sum(s);
+      const float mu = s * (1.0f / WC);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) { const float d = v[i][k] - mu; q = fmaf(d, d, q); }
+      q = rows_sum(q);
+      const float rs = rsqrtf(q * (1.0f / WC) + 1e-5f);
+      if (valid) {
+        if (SAVE && g == 0) *(float2*)((unsigned char*)a.st2 + myrow * 8u) = make_float2(mu, rs);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *(uint4*)(a.xm + (myoff + 64u * i)) = pack<T>(v[i]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          float f[KPL], ga[KPL], be[KPL];
+#pragma unroll
+          for (int k = 0; k < KPL; k += 4) {
+            *(f32x4*)(ga + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (3 * WC + 4 * i * KPL + k) * 4);
+            *(f32x4*)(be + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (4 * WC + 4 * i * KPL + k) * 4);
+          }
+#pragma unroll
+          for (int k = 0; k < KPL; ++k) f[k] = fmaf((v[i][k] - mu) * rs, ga[k], be[k]);
+          *(uint4*)(a.xn2 + (myoff + 64u * i)) = pack<T>(f);
+        }
+      } else {
+        HG_VMWAIT(0);                                    // (no stores were issued: the counted wait of the next prologue must not run short)
+      }
+    }
+  }
+  HG_VMWAIT(0);
+}
+
+template <bool SAVE>
+int hg_launch(const WArgs& a, hipStream_t st) {
+  constexpr int LDS = SAVE ? HG_LDS_SAVE : HG_LDS_INF;
+  static bool attr_set = false;
+  auto kern = wmsa_hg_kernel<SAVE>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      (void)hipGetLastError();
+      return SODT_EINVAL;
+    }
+    attr_set = true;
+  }
+  const int npairs = (a.nwin + 1) / 2;
+  const int grid = npairs < 256 ? npairs : 256;          // one workgroup per CU, persistent over the window pairs
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, a);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+}  // namespace
+
+int wmsa_hg_launch(const WArgs& a, bool save, hipStream_t st) {
+  return save ? hg_launch<true>(a, st) : hg_launch<false>(a, st);
+}
