@@ -161,6 +161,8 @@ int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, void* xn2, flo
                         int B, int H, int W, int C, int heads, int ws, int shift, int dtype, sodt_stream_t st);
 /* diagnostic hook: per-phase shader-cycle sums of the instrumented bf16 build (see csrc/wmsa_block.hip) */
 int sodt_debug_wmsa_stamps(long long* out_host_256x8, int enable);
+/* the same for the four-waves-per-window bf16 kernel (csrc/wmsa_hg.hip): 12 phases per workgroup */
+int sodt_debug_wmsa_hg_stamps(long long* out_host_512x12, int enable);
 /* sodt_window_attn_bwd on the window-major qkvw / lsew of sodt_wmsa_block_fwd (8x8 windows, head_dim 16);
  * dout and dqkv keep the natural layouts [M][C] / [M][3C]. */
 int sodt_window_attn_bwd_wm(const void* qkvw, const float* bias_t, const void* dout, const float* lsew,

@@ -614,6 +614,8 @@ __global__ __launch_bounds__(256) void wmsa_pack_kernel(const float* __restrict_
     for (int e = tid; e < L::KSTEPS * 64 * KPL; e += 256) {
       const int kk = e / (64 * KPL), l = (e / KPL) % 64, j = e % KPL;
       dst[e] = from_f<T>(qkv_w[(long)(sect * WC + WHD * h + (l & 15)) * WC + KU * kk + KPL * (l >> 4) + j]);
+      if constexpr (L::HGW_BYTES > 0)      // the same fragments in the contiguous stream of wmsa_hg.hip
+        ((T*)(wpk + L::HGW_OFF + (long)h * 3 * L::WFRAG + sect * L::WFRAG))[e] = dst[e];
     }
   }
   // relative-position bias of this head x log2 e: copy v, row dyi, position i holds table[dyi][14 - (i + v)]
@@ -689,6 +691,7 @@ extern "C" int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, voi
   a.x = (const unsigned char*)x; a.wpk = (const unsigned char*)wpk;
   a.xm = (unsigned char*)xm; a.xn2 = (unsigned char*)xn2; a.st1 = st1; a.st2 = st2;
   a.xn1 = (unsigned char*)xn1; a.qkvw = (unsigned char*)qkvw; a.lsew = lsew; a.ao = (unsigned char*)ao;
+  a.dbg = 0;
   a.B = B; a.H = H; a.W = W; a.shift = shift; a.nwy = H / WWS; a.nwx = W / WWS; a.nwin = B * a.nwy * a.nwx;
   hipStream_t st = (hipStream_t)st_;
   if (dtype == SODT_BF16) {

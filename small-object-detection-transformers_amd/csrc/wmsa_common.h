@@ -11,6 +11,7 @@ struct WArgs {
   unsigned char* xm; unsigned char* xn2; float* st1; float* st2;
   unsigned char* xn1; unsigned char* qkvw; float* lsew; unsigned char* ao;
   int B, H, W, shift, nwy, nwx, nwin;
+  int dbg;      // diagnostic ablations of wmsa_hg.hip (SODT_HG_DBG; results are wrong when non-zero): 1 = no weight DMA after the first, 2 = no output stores
 };
 int wmsa_hg_launch(const WArgs& a, bool save, hipStream_t st);     // wmsa_hg.hip
 
@@ -42,10 +43,14 @@ template <typename T> struct WL {
   static constexpr int STAGE = PROJ_BYTES > HEAD_BYTES ? PROJ_BYTES : HEAD_BYTES;
   static constexpr int NSTG = WHEADS + 3;                // stages per block: 12 heads + 3 projection stages
   static constexpr int TAIL_OFF = NSTG * STAGE;          // bproj[192], g1, b1, g2, b2: f32
-  // bf16 only: Wproj again in NATURAL k order for the four-waves-per-window kernel (wmsa_hg.hip: its projection reads the
-  // attention output from an LDS tile, 8 consecutive channels per lane): strip n, k-step kp = one 1 KB fragment, lane
-  // (g, t): row 16 n + t, columns 32 kp + 8 g + j
-  static constexpr int PROJ2_OFF = TAIL_OFF + 5 * WC * 4;
+  // bf16 only: the weights again as ONE contiguous 288 KB stream for the four-waves-per-window kernel (wmsa_hg.hip), four
+  // 72 KB stages it copies into LDS by DMA: stages 0..2 = Wq | Wk | Wv fragments of heads 4 s .. 4 s + 3 (18 KB per head,
+  // the first 18 KB of the per-head stages above), stage 3 = Wproj in NATURAL k order (its projection reads the attention
+  // output from an LDS tile, 8 consecutive channels per lane): strip n, k-step kp = one 1 KB fragment, lane (g, t): row
+  // 16 n + t, columns 32 kp + 8 g + j
+  static constexpr int HGW_OFF = TAIL_OFF + 5 * WC * 4;
+  static constexpr int HGW_BYTES = E == 2 ? WHEADS * 3 * WFRAG : 0;       // 221184 / 0
+  static constexpr int PROJ2_OFF = HGW_OFF + HGW_BYTES;
   static constexpr int PROJ2_BYTES = E == 2 ? WHEADS * KP * 1024 : 0;     // 73728 / 0
   static constexpr int PACK_BYTES = PROJ2_OFF + PROJ2_BYTES;
   static constexpr int XNB = 64 * ROWB;                  // one wave's LN1 tile: 24 KB / 48 KB

@@ -25,6 +25,7 @@
 //
 // LDS: 2 x 24 KB tiles + 72 KB weights + 25.5 KB tables + 3.75 KB vectors (+ 8 KB v patches when saving) = 157.25 KB.
 #include "wmsa_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -40,7 +41,16 @@ constexpr int HG_LDS_INF = HG_VP_OFF, HG_LDS_SAVE = HG_VP_OFF + 8 * 1024;
 static_assert(HG_LDS_SAVE <= 160 * 1024, "LDS budget");
 static_assert(WL<bf16>::STAGE == 24576 && WL<bf16>::BIAS_OFF == HG_HEADW && WL<bf16>::BQKV_OFF == HG_HEADW + 1920, "pack layout");
 
-template <bool SAVE>
+// STAMP: diagnostic build (sodt_debug_wmsa_hg_stamps): wave 0 of every workgroup sums shader cycles per phase
+__device__ long long g_hg_stamps[512][12];     // rows 0..255: wave 0 (window A, older), 256..511: wave 4 (window B, same SIMD)
+__device__ __forceinline__ long long hg_now() {
+  long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define HG_STAMP(i) do { if constexpr (STAMP) { const long long now_ = hg_now(); acc_st[i] += now_ - last_st; last_st = now_; } } while (0)
+
+template <bool SAVE, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
   typedef bf16 T;
   using L = WL<bf16>;
@@ -65,19 +75,26 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
   const int j0 = 7 - (t & 7) + 4 * (g & 1), jv = j0 & 3;
   const int bias_lane_off = (((jv * 15 + (t >> 3) - (g >> 1) + 7) * 16) + (j0 - jv)) * E;
 
-  // ---- weights: LDS-DMA of 72 one-KB pieces, nine per wave.  stage 0..2: Wq|Wk|Wv fragments of heads 4 s .. 4 s + 3 (the
-  // first 18 KB of their pack stages), stage 3: Wproj in natural k order
-  auto dma_w = [&](int stage) {
+  // ---- weights: LDS-DMA of 72 one-KB pieces, nine per wave.  stage 0..2: Wq|Wk|Wv fragments of heads 4 s .. 4 s + 3,
+  // stage 3: Wproj in natural k order (WL::HGW_OFF)
+  const int rot = (int)((blockIdx.x >> 3) * 7 + (blockIdx.x & 7) * 3) % 72;     // (blocks b, b + 8, ... share an XCD: distinct rotations)
+  // pieces q0 .. q1 - 1 of this wave's nine: the issue of a 1 KB piece stalls the wave for 100+ cycles while the CU's address
+  // path works through the burst, so the nine are spread over the VALU work of the phase that hides the copy
+  auto dma_part = [&](int stage, int q0, int q1) {
+    if (a.dbg & 1) return;
+    const unsigned char* gsrc = a.wpk + L::HGW_OFF + (size_t)stage * HG_WBUF;     // the stages are one contiguous stream
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const int p = w + 8 * q;
-      const unsigned char* gsrc = stage < 3 ? a.wpk + (size_t)(4 * stage + p / 18) * L::STAGE + (size_t)(p % 18) * 1024
-                                            : a.wpk + L::PROJ2_OFF + (size_t)p * 1024;
-      const unsigned ldst = smem0 + HG_WBUF_OFF + (unsigned)(p * 1024);
+    for (int q = q0; q < q1; ++q) {
+      // (the piece order is rotated per workgroup: every CU streams the same 72 KB, and walking it in the same order at the
+      //  same time piles the requests of an XCD's 32 CUs onto one L2 channel after the other)
+      int p = w + 8 * q + rot;
+      p = p >= 72 ? p - 72 : p;
+      const unsigned off = (unsigned)p << 10;
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                   :: "v"((unsigned)(lane * 16)), "s"(gsrc), "s"(ldst) : "memory", "m0");
+                   :: "v"((unsigned)(lane * 16) + off), "s"(gsrc), "s"(smem0 + HG_WBUF_OFF + off) : "memory", "m0");
     }
   };
+  auto dma_w = [&](int stage) { dma_part(stage, 0, 9); };
 #define HG_VMWAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
   dma_w(0);
@@ -97,18 +114,32 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
     const int wy_ = item % a.nwy; const int b_ = item / a.nwy;
     return (unsigned)wtoken(a, b_, wy_, wx_, 16 * j + t);
   };
-  uint4 xc[6];
+  uint4 xc[6], xnext[6];      // x of this wave's 16 tokens: the current pair's (LN1 input AND residual) and the next pair's
   if ((int)blockIdx.x < npairs) {
     const unsigned ro = row_of(blockIdx.x) * (unsigned)ROWB + (unsigned)(g * 16);
 #pragma unroll
     for (int i = 0; i < 6; ++i) xc[i] = *(const uint4*)(a.x + (ro + 64u * i));
   }
-  // LDS row of this lane in the token-major phases
-  const unsigned trow = tile + (unsigned)((16 * j + t) * ROWB);
-  lds_u8* const p_rE = sm3 + trow + gx3 + swb;           // chunk 4 i + g: even i at +64 b, odd i at -64 b (+ 64 i)
-  lds_u8* const p_rO = sm3 + trow + gx3 - swb;
-  lds_u8* const p_ln = sm3 + HG_LNV_OFF + g * KPL * 4;   // this lane's first channel inside a 4-chunk group
+  // Per-lane addresses of the token-major phases, the tile hand-overs and the output rows are re-derived from a LAUNDERED lane
+  // id where they are used: as loop invariants they would stay live across the head steps - hipcc spills them - while
+  // re-deriving costs a few VALU instructions per window pair.
+  // token-major phases: this lane's LDS row (token 16 j + t of the window), chunk 4 i + g: even i at +64 b, odd i at -64 b (+ 64 i)
+#define HG_TOKEN_PTRS()                                                                                   \
+  int ll_ = lane; LAUNDER(ll_);                                                                           \
+  const int tl = ll_ & 15, gl = ll_ >> 4;                                                                 \
+  const unsigned trow_ = tile + (unsigned)((16 * j + tl) * ROWB) + (unsigned)((gl ^ (tl & 3)) << 4);      \
+  const unsigned swb_ = (unsigned)(((tl >> 2) & 1) * 64);                                                 \
+  lds_u8* const p_rE = sm3 + trow_ + swb_; lds_u8* const p_rO = sm3 + trow_ - swb_;                       \
+  lds_u8* const p_ln = sm3 + HG_LNV_OFF + gl * KPL * 4;                                                   \
+  const unsigned myrow = (unsigned)wtoken(a, b, wy, wx, 16 * j + tl);                                     \
+  const unsigned myoff = myrow * (unsigned)ROWB + (unsigned)(gl * 16)
+  // bias tables of this wave's heads 4 step + j: one base per lane, the step is an immediate offset
+  const unsigned tbl = smem0 + HG_TAB_OFF + (unsigned)(j * HG_TABH);
+  const unsigned bb3 = tbl + (unsigned)bias_lane_off - (unsigned)(3 * 2 * 16 * E);
+  const unsigned sbg = tbl + 1920u + (unsigned)(16 * g), sbt = tbl + 1920u + (unsigned)(4 * t);
   __syncthreads();
+  long long acc_st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_st = 0;
+  if constexpr (STAMP) last_st = hg_now();
 
   for (int it = blockIdx.x; it < npairs; it += gridDim.x) {
     int item = 2 * it + ww;
@@ -119,8 +150,6 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
     const int wy = tq % a.nwy; const int b = tq / a.nwy;
     const bool msk = a.shift > 0 && (wy == a.nwy - 1 || wx == a.nwx - 1);
     const unsigned whoff = (unsigned)item * WHEADS;
-    const unsigned myrow = (unsigned)wtoken(a, b, wy, wx, 16 * j + t);
-    const unsigned myoff = myrow * (unsigned)ROWB + (unsigned)(g * 16);
     unsigned diffm[4] = {0u, 0u, 0u, 0u};
     if (msk) {
       int kr[16];
@@ -136,6 +165,7 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
 
     // ================= prologue: LN1 of this wave's 16 tokens -> tile rows 16 j .. 16 j + 15
     {
+      HG_TOKEN_PTRS();
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -156,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
       }
       q = rows_sum(q);
       const float rstd = rsqrtf(q * (1.0f / WC) + 1e-5f);
-      if (SAVE && valid && g == 0) *(float2*)((unsigned char*)a.st1 + myrow * 8u) = make_float2(mu, rstd);
+      if (SAVE && valid && gl == 0) *(float2*)((unsigned char*)a.st1 + myrow * 8u) = make_float2(mu, rstd);
       wave_sync();                                       // this wave's epilogue reads of the same rows are done
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -176,46 +206,41 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
     }
     // W(0) was requested before the previous pair's epilogue stores (or at kernel start): everything older than the
     // youngest stores has landed.  The stores themselves stay in flight.
+    HG_STAMP(0);
     if (SAVE) HG_VMWAIT(0); else HG_VMWAIT(12);
     __syncthreads();                                     // B1: tiles complete, W(0) visible
+    HG_STAMP(1);
 
     k16_t poall[3][4];
     static_for<0, 3>([&](auto i_) {
       constexpr int step = decltype(i_)::value;
       const int h = 4 * step + j;
-      const unsigned tb = smem0 + HG_TAB_OFF + (unsigned)(h * HG_TABH);
-      const unsigned bb3 = tb + (unsigned)bias_lane_off - (unsigned)(3 * 2 * 16 * E);
-      const unsigned sbg = tb + 1920u + (unsigned)(16 * g), sbt = tb + 1920u + (unsigned)(4 * t);
+      constexpr int TBO = step * 4 * HG_TABH;            // table / bias of head 4 step + j relative to the lane bases
       typedef typename KR<T>::type kreg_t;
       // ---- q^T, k^T (channel rows, token columns) and v (token rows, channel columns) of head h
-      u32x4_ bqr = lds_rd128a<0>(sbg), bkr = lds_rd128a<64>(sbg);
-      unsigned bvr = lds_rd32a<128>(sbt);
-      kreg_t biar[7];
-      static_for<0, 7>([&](auto d_) { constexpr int d = decltype(d_)::value; biar[d] = KR<T>::template rd<d * 2 * 16 * E>(bb3); });
-      u32x4_ wf[2][3], xf[2][4];
+      u32x4_ bqr = lds_rd128a<TBO>(sbg), bkr = lds_rd128a<TBO + 64>(sbg);
+      unsigned bvr = lds_rd32a<TBO + 128>(sbt);
+      // fragments are single-buffered: the reads of k-step kk + 1 are issued right after the MFMAs of k-step kk (which
+      // have taken their operands) and land while those execute; the SIMD's second wave fills what is left of the gap
+      u32x4_ wf[3], xf[4];
       auto issue_k = [&](auto kk_) {
-        constexpr int kk = decltype(kk_)::value, bsel = kk & 1;
-        wf[bsel][0] = lds_rd128a<0 + kk * 1024>(wb16);
-        wf[bsel][1] = lds_rd128a<6144 + kk * 1024>(wb16);
-        wf[bsel][2] = lds_rd128a<12288 + kk * 1024>(wb16);
+        constexpr int kk = decltype(kk_)::value;
+        wf[0] = lds_rd128a<0 + kk * 1024>(wb16);
+        wf[1] = lds_rd128a<6144 + kk * 1024>(wb16);
+        wf[2] = lds_rd128a<12288 + kk * 1024>(wb16);
         static_for<0, 4>([&](auto ms_) {
           constexpr int ms = decltype(ms_)::value;
-          xf[bsel][ms] = lds_rd128a<ms * 16 * ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
+          xf[ms] = lds_rd128a<ms * 16 * ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
         });
       };
       issue_k(std::integral_constant<int, 0>{});
       k16_t pq[4], pqs[4], pkk[4], pv[4];
       f32x4 qT[4], kT[4], vv[4];
       static_for<0, 6>([&](auto kk_) {
-        constexpr int kk = decltype(kk_)::value, bsel = kk & 1;
-        if constexpr (kk + 1 < 6) {
-          issue_k(std::integral_constant<int, kk + 1>{});
-          LDS_WAIT(7);
-        } else {
-          LDS_WAIT(0);
-        }
-        LDS_DEP(wf[bsel][0]); LDS_DEP(wf[bsel][1]); LDS_DEP(wf[bsel][2]);
-        LDS_DEP(xf[bsel][0]); LDS_DEP(xf[bsel][1]); LDS_DEP(xf[bsel][2]); LDS_DEP(xf[bsel][3]);
+        constexpr int kk = decltype(kk_)::value;
+        LDS_WAIT(0);
+        LDS_DEP(wf[0]); LDS_DEP(wf[1]); LDS_DEP(wf[2]);
+        LDS_DEP(xf[0]); LDS_DEP(xf[1]); LDS_DEP(xf[2]); LDS_DEP(xf[3]);
         if constexpr (kk == 0) {
           LDS_DEP(bqr); LDS_DEP(bkr); LDS_DEP(bvr);
           const f32x4 bqv = KR<float>::f4(bqr), bkv = KR<float>::f4(bkr);
@@ -223,30 +248,29 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
 #pragma unroll
           for (int ms = 0; ms < 4; ++ms) { qT[ms] = bqv; kT[ms] = bkv; vv[ms] = f32x4{bvs, bvs, bvs, bvs}; }
         }
-        const uint4 wq = u4(wf[bsel][0]), wk = u4(wf[bsel][1]), wv = u4(wf[bsel][2]);
+        const uint4 wq = u4(wf[0]), wk = u4(wf[1]), wv = u4(wf[2]);
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
-          const uint4 x4 = u4(xf[bsel][ms]);
+          const uint4 x4 = u4(xf[ms]);
           mma16<T>(qT[ms], wq, x4);
           mma16<T>(kT[ms], wk, x4);
           mma16<T>(vv[ms], x4, wv);
         }
+        if constexpr (kk + 1 < 6) issue_k(std::integral_constant<int, kk + 1>{});
       });
+      // the head's bias-table entries (7 x 4 per lane): requested now, used after the hand-over barrier
+      kreg_t biar[7];
+      static_for<0, 7>([&](auto d_) { constexpr int d = decltype(d_)::value; biar[d] = KR<T>::template rd<TBO + d * 2 * 16 * E>(bb3); });
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms) {
         if (SAVE) pq[ms] = pk16<T>(qT[ms]);
         pqs[ms] = pk16<T>(qT[ms] * scale2);              // hd^-1/2 x log2 e folded into q: S^T leaves the MFMA ready for exp2
         pkk[ms] = pk16<T>(kT[ms]); pv[ms] = pk16<T>(vv[ms]);
       }
+      HG_STAMP(2);
       __syncthreads();                                   // B2/4/6: everyone is done with the weight buffer (step 2: and the LN1 tile)
-      dma_w(step + 1);                                   // next heads' weights / Wproj land under the softmax
-      if constexpr (step == 2) {
-        // x of the NEXT window pair: requested now, consumed by the next prologue
-        const int nx = it + (int)gridDim.x < npairs ? it + (int)gridDim.x : it;
-        const unsigned ro = row_of(nx) * (unsigned)ROWB + (unsigned)(g * 16);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) xc[i] = *(const uint4*)(a.x + (ro + 64u * i));
-      }
+      HG_STAMP(3);
+      dma_part(step + 1, 0, 3);                          // next heads' weights / Wproj land under the softmax (pieces 3..8: inside it)
       if (SAVE && valid) {
         unsigned char* qb = a.qkvw + (size_t)(whoff + h) * (3 * 64 * WHD * E);     // uniform
         const unsigned lo = (unsigned)(t * (WHD * E) + g * 8);
@@ -272,10 +296,12 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
         }
       }
 
+      HG_STAMP(4);
       auto body = [&](auto MSK_) {
         constexpr bool MSK = decltype(MSK_)::value;
         // ---- S^T = K Q^T: row = key 16 ks + 4 g + r, column = query 16 ms + t; the bias is the accumulator's initial value
         f32x4 bia[7];
+        LDS_WAIT(0);
 #pragma unroll
         for (int d = 0; d < 7; ++d) { LDS_DEP(biar[d]); bia[d] = KR<T>::f4(biar[d]); }
         k16_t pp[4][4];                                  // P^T strips, packed: [ks][ms]
@@ -303,6 +329,7 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
           }
           sum = rows_sum(sum);
           inv[ms] = __builtin_amdgcn_rcpf(sum);
+          if (ms < 3) dma_part(step + 1, 3 + 2 * ms, 5 + 2 * ms);
           if (SAVE && valid && g == 0)
             (a.lsew + (size_t)(whoff + h) * 64)[16 * ms + t] = mx * (1.0f / WMSA_LOG2E) + __logf(sum);
         }
@@ -319,28 +346,35 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
         }
       };
       if (msk) body(std::true_type{}); else body(std::false_type{});
+      HG_STAMP(5);
 
       if constexpr (step < 2) {
         HG_VMWAIT(0);                                    // this wave's pieces of the next weights have landed
         __syncthreads();                                 // B3/5
+        HG_STAMP(6);
       }
     });
 
     // ================= O^T of this wave's three heads -> the (dead) LN1 tile, now the attention-output tile [64][192]
     // (every wave passed B6 after its last QKV phase: nobody reads LN1 rows any more)
+    {
+      // head 4 step + j, channels 4 g .. 4 g + 3 of token (ms, t): chunk 2 h + (g >> 1) = 8 step + (2 j + (g >> 1)), stored
+      // at chunk ^ (t & 7): the step is a +128-byte immediate
+      int ll_ = lane; LAUNDER(ll_);
+      const int tl = ll_ & 15, gl = ll_ >> 4;
+      lds_u8* const p_ao = sm3 + tile + tl * ROWB + (((2 * j + (gl >> 1)) ^ (tl & 7)) << 4) + 8 * (gl & 1);
 #pragma unroll
-    for (int step = 0; step < 3; ++step) {
-      const int h = 4 * step + j;
-      const int cw = 2 * h + (g >> 1);
+      for (int step = 0; step < 3; ++step)
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms)
-        *(__attribute__((address_space(3))) u32x2_*)(sm3 + tile + (16 * ms + t) * ROWB + ((cw ^ (t & 7)) << 4) + 8 * (g & 1)) =
-            u32x2_{poall[step][ms].x, poall[step][ms].y};
+        for (int ms = 0; ms < 4; ++ms)
+          *(__attribute__((address_space(3))) u32x2_*)(p_ao + ms * 16 * ROWB + 128 * step) = u32x2_{poall[step][ms].x, poall[step][ms].y};
     }
-    HG_VMWAIT(6);                                        // Wproj has landed (the six x loads of the next pair were issued after it)
+    HG_VMWAIT(0);                                        // Wproj has landed
     __syncthreads();                                     // B7: attention-output tiles complete, Wproj visible
+    HG_STAMP(7);
 
     if (SAVE && valid) {                                 // attention output, natural token order (operand of the dWproj GEMM)
+      HG_TOKEN_PTRS();
 #pragma unroll
       for (int i = 0; i < 6; ++i)
         *(uint4*)(a.ao + (myoff + 64u * i)) = u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)(((i & 1) ? p_rO : p_rE) + 64 * i));
@@ -348,32 +382,28 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
     // ================= output projection: out^T rows 48 j .. 48 j + 47 (three 16-row strips) x 64 tokens, K = 192
     f32x4 oT[3][4];
     {
-      u32x4_ wf[2][3], xf[2][4];
+      u32x4_ wf[3], xf[4];
       auto issue_k = [&](auto kk_) {
-        constexpr int kk = decltype(kk_)::value, bsel = kk & 1;
-        wf[bsel][0] = lds_rd128a<0 + kk * 1024>(wb16);
-        wf[bsel][1] = lds_rd128a<6144 + kk * 1024>(wb16);
-        wf[bsel][2] = lds_rd128a<12288 + kk * 1024>(wb16);
+        constexpr int kk = decltype(kk_)::value;
+        wf[0] = lds_rd128a<0 + kk * 1024>(wb16);
+        wf[1] = lds_rd128a<6144 + kk * 1024>(wb16);
+        wf[2] = lds_rd128a<12288 + kk * 1024>(wb16);
         static_for<0, 4>([&](auto ms_) {
           constexpr int ms = decltype(ms_)::value;
-          xf[bsel][ms] = lds_rd128a<ms * 16 * ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
+          xf[ms] = lds_rd128a<ms * 16 * ROWB + 64 * kk>((kk & 1) ? xfO : xfE);
         });
       };
       // projection bias of this lane's channels 16 (3 j + nl) + 4 g .. + 3: the accumulators' initial value
-      const unsigned pbb = smem0 + HG_LNV_OFF + (unsigned)((48 * j + 4 * g) * 4);
+      int llp = lane; LAUNDER(llp);
+      const unsigned pbb = smem0 + HG_LNV_OFF + (unsigned)((48 * j + 4 * (llp >> 4)) * 4);
       u32x4_ pbr[3];
       pbr[0] = lds_rd128a<0>(pbb); pbr[1] = lds_rd128a<64>(pbb); pbr[2] = lds_rd128a<128>(pbb);
       issue_k(std::integral_constant<int, 0>{});
       static_for<0, 6>([&](auto kk_) {
-        constexpr int kk = decltype(kk_)::value, bsel = kk & 1;
-        if constexpr (kk + 1 < 6) {
-          issue_k(std::integral_constant<int, kk + 1>{});
-          LDS_WAIT(7);
-        } else {
-          LDS_WAIT(0);
-        }
-        LDS_DEP(wf[bsel][0]); LDS_DEP(wf[bsel][1]); LDS_DEP(wf[bsel][2]);
-        LDS_DEP(xf[bsel][0]); LDS_DEP(xf[bsel][1]); LDS_DEP(xf[bsel][2]); LDS_DEP(xf[bsel][3]);
+        constexpr int kk = decltype(kk_)::value;
+        LDS_WAIT(0);
+        LDS_DEP(wf[0]); LDS_DEP(wf[1]); LDS_DEP(wf[2]);
+        LDS_DEP(xf[0]); LDS_DEP(xf[1]); LDS_DEP(xf[2]); LDS_DEP(xf[3]);
         if constexpr (kk == 0) {
           LDS_DEP(pbr[0]); LDS_DEP(pbr[1]); LDS_DEP(pbr[2]);
 #pragma unroll
@@ -383,39 +413,55 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
         }
 #pragma unroll
         for (int nl = 0; nl < 3; ++nl) {
-          const uint4 wa = u4(wf[bsel][nl]);
+          const uint4 wa = u4(wf[nl]);
 #pragma unroll
-          for (int ms = 0; ms < 4; ++ms) mma16<T>(oT[nl][ms], wa, u4(xf[bsel][ms]));
+          for (int ms = 0; ms < 4; ++ms) mma16<T>(oT[nl][ms], wa, u4(xf[ms]));
         }
+        if constexpr (kk + 1 < 6) issue_k(std::integral_constant<int, kk + 1>{});
       });
     }
+    HG_STAMP(8);
     __syncthreads();                                     // B8: everyone is done with the attention-output tile and Wproj
+    HG_STAMP(9);
 
-    // residual x of this wave's 16 tokens, then the first weights of the next pair: both before the output stores
-    uint4 xr[6];
+    // the first weights and the x rows of the next pair: requested before the output stores (a load queued behind a store
+    // waits for the store's acknowledgement), consumed by the next prologue
+    const bool more = it + (int)gridDim.x < npairs;
+    {
+      const int nx = it + (int)gridDim.x < npairs ? it + (int)gridDim.x : it;
+      const unsigned ro = row_of(nx) * (unsigned)ROWB + (unsigned)(g * 16);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) xr[i] = *(const uint4*)(a.x + (myoff + 64u * i));
-    dma_w(0);
+      for (int i = 0; i < 6; ++i) xnext[i] = *(const uint4*)(a.x + (ro + 64u * i));
+    }
     // out^T (+ bias) -> tile, run dtype: the rounding a separate projection launch applies to its output
+    {
+      int ll_ = lane; LAUNDER(ll_);
+      const int tl = ll_ & 15, gl = ll_ >> 4;
+      lds_u8* const p_t = sm3 + tile + tl * ROWB + 8 * (gl & 1);
 #pragma unroll
-    for (int nl = 0; nl < 3; ++nl) {
-      const int cw = 2 * (3 * j + nl) + (g >> 1);
+      for (int nl = 0; nl < 3; ++nl) {
+        if (more) dma_part(0, 3 * nl, 3 * nl + 3);
+        const int cw = 2 * (3 * j + nl) + (gl >> 1);
+        lds_u8* const p_o = p_t + ((cw ^ (tl & 7)) << 4);
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms) {
-        const k16_t v = pk16<T>(oT[nl][ms]);
-        *(__attribute__((address_space(3))) u32x2_*)(sm3 + tile + (16 * ms + t) * ROWB + ((cw ^ (t & 7)) << 4) + 8 * (g & 1)) = u32x2_{v.x, v.y};
+        for (int ms = 0; ms < 4; ++ms) {
+          const k16_t v = pk16<T>(oT[nl][ms]);
+          *(__attribute__((address_space(3))) u32x2_*)(p_o + ms * 16 * ROWB) = u32x2_{v.x, v.y};
+        }
       }
     }
     __syncthreads();                                     // B9: output tiles complete
+    HG_STAMP(10);
 
     // ================= epilogue: x_mid = x + (out + bproj), xn2 = LN2(x_mid) for this wave's 16 tokens
     {
+      HG_TOKEN_PTRS();
       float v[6][KPL];
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         float f[KPL], o[KPL];
-        unpack<T>(xr[i], f);
+        unpack<T>(xc[i], f);                             // residual: the x this wave loaded for LN1, still in registers
         unpack<T>(u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)(((i & 1) ? p_rO : p_rE) + 64 * i)), o);
         // x_mid is stored in bf16: LN2 normalises the ROUNDED value, as a separate LayerNorm launch reading x_mid would
 #pragma unroll
@@ -430,8 +476,8 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
         for (int k = 0; k < KPL; ++k) { const float d = v[i][k] - mu; q = fmaf(d, d, q); }
       q = rows_sum(q);
       const float rs = rsqrtf(q * (1.0f / WC) + 1e-5f);
-      if (valid) {
-        if (SAVE && g == 0) *(float2*)((unsigned char*)a.st2 + myrow * 8u) = make_float2(mu, rs);
+      if (valid && !(a.dbg & 2)) {
+        if (SAVE && gl == 0) *(float2*)((unsigned char*)a.st2 + myrow * 8u) = make_float2(mu, rs);
 #pragma unroll
         for (int i = 0; i < 6; ++i) *(uint4*)(a.xm + (myoff + 64u * i)) = pack<T>(v[i]);
 #pragma unroll
@@ -450,15 +496,24 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
         HG_VMWAIT(0);                                    // (no stores were issued: the counted wait of the next prologue must not run short)
       }
     }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xc[i] = xnext[i];
+    HG_STAMP(11);
   }
   HG_VMWAIT(0);
+  if constexpr (STAMP) {
+    if ((tid == 0 || tid == 256) && blockIdx.x < 256)
+      for (int i = 0; i < 12; ++i) g_hg_stamps[blockIdx.x + (tid ? 256 : 0)][i] = acc_st[i];
+  }
 }
 
-template <bool SAVE>
+bool g_hg_stamp_enable = false;
+
+template <bool SAVE, bool STAMP = false>
 int hg_launch(const WArgs& a, hipStream_t st) {
   constexpr int LDS = SAVE ? HG_LDS_SAVE : HG_LDS_INF;
   static bool attr_set = false;
-  auto kern = wmsa_hg_kernel<SAVE>;
+  auto kern = wmsa_hg_kernel<SAVE, STAMP>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       (void)hipGetLastError();
@@ -474,6 +529,20 @@ int hg_launch(const WArgs& a, hipStream_t st) {
 
 }  // namespace
 
-int wmsa_hg_launch(const WArgs& a, bool save, hipStream_t st) {
+int wmsa_hg_launch(const WArgs& a_, bool save, hipStream_t st) {
+  WArgs a = a_;
+  static const int dbg = getenv("SODT_HG_DBG") ? atoi(getenv("SODT_HG_DBG")) : 0;
+  a.dbg = dbg;
+  if (g_hg_stamp_enable) return save ? hg_launch<true, true>(a, st) : hg_launch<false, true>(a, st);
   return save ? hg_launch<true>(a, st) : hg_launch<false>(a, st);
+}
+
+/* diagnostic hook (tools/mb_wmsa.py --hg-stamps): enable != 0 makes the following bf16 launches run the instrumented build; out
+ * (host, 512 x 12 long long, nullable: rows 0..255 wave 0, 256..511 wave 4) receives the per-phase shader-cycle sums of wave 0 of each workgroup of the last such
+ * launch: [LN1, B1 wait, QKV, B2/4/6 wait, dma issue + saves, softmax + PV, B3/5 wait, O^T -> tile + B7, projection, B8 wait,
+ * residual loads + staging + B9, epilogue] */
+extern "C" int sodt_debug_wmsa_hg_stamps(long long* out, int enable) {
+  g_hg_stamp_enable = enable != 0;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hg_stamps), sizeof(long long) * 512 * 12) != hipSuccess) return SODT_EINVAL;
+  return SODT_OK;
 }

@@ -67,3 +67,21 @@ if "--stamps" in sys.argv:
         for i, n in enumerate(names):
             per = t[:, i].mean() / (M / 64 / 1024 * (12 if i < 6 else 1))
             print(f"   {n:14s} {t[:, i].mean():12.0f} cycles = {100 * t[:, i].mean() / tot:5.1f} %   ({per:8.0f} per {'head' if i < 6 else 'window'})")
+
+if "--hg-stamps" in sys.argv:
+    import ctypes
+    lib = L.load()
+    names = ["LN1", "B1 wait", "QKV", "B2/4/6 wait", "dma issue+saves", "softmax+PV", "B3/5 wait", "O^T->tile + B7", "projection",
+             "B8 wait", "resid+staging+B9", "epilogue"]
+    for label, fn in (("inference", lambda: ops.wmsa_block_fwd(x, wpk, xm, xn2, None, None, None, None, None, None, B, H, H, C, HEADS, WS, 0)),
+                      ("training", lambda: ops.wmsa_block_fwd(x, wpk, xm, xn2, st1, st2, xn1, qkvw, lsew, ao, B, H, H, C, HEADS, WS, 0))):
+        lib.sodt_debug_wmsa_hg_stamps(None, 1)
+        fn(); torch.cuda.synchronize(); big.zero_(); fn(); torch.cuda.synchronize()
+        buf = (ctypes.c_longlong * (512 * 12))()
+        lib.sodt_debug_wmsa_hg_stamps(buf, 0)
+        t2 = torch.tensor(list(buf), dtype=torch.float64).view(2, 256, 12)
+        npair = M / 64 / 2 / 256
+        tot = t2[0].sum(1).mean()
+        print(f"hg stamps ({label}; mean over 256 workgroups; cycles per launch {tot:.0f}, {tot / npair:.0f} per window pair); per pair: wave 0 | wave 4")
+        for i, n in enumerate(names):
+            print(f"   {n:20s} {t2[0][:, i].mean() / npair:8.0f} ({100 * t2[0][:, i].mean() / tot:5.1f} %) | {t2[1][:, i].mean() / npair:8.0f}")
