@@ -286,6 +286,14 @@ int sodt_sgd_ema_step(float* p, const float* g, float* mom, float* ema, void* p_
                       const float* momentum, const float* weight_decay, int nesterov, float grad_scale,
                       float ema_decay, sodt_stream_t st);
 
+/* Input pre-processing of the training / evaluation loop (csrc/preprocess.hip): `imgs.to(device).float() / 255.0` followed by
+ * `F.interpolate(image, size=[i // down_factor ...], mode='bilinear', align_corners=True)` (Train.py:364-374; test.py:124-129
+ * is the factor-1 case) for the RGB and the IR batch in one launch.  rgb / ir: uint8 (B, c, Hin, Win) contiguous (device);
+ * out_rgb / out_ir: f32 (B, c, Hout, Wout), the planes sodt_frontend_fwd reads.  Hout <= Hin, Wout <= Win; Hout == Hin is
+ * the plain u8 -> f32 / 255.  c_ir may be 0 (ir, out_ir then unused). */
+int sodt_preprocess_u8(const unsigned char* rgb, const unsigned char* ir, float* out_rgb, float* out_ir, int B, int c_rgb,
+                       int c_ir, int Hin, int Win, int Hout, int Wout, sodt_stream_t st);
+
 /* ComputeLoss.__call__ + build_targets (basics/utils/loss.py:116-224) with bbox_iou(CIoU) (basics/utils/general.py:347-389)
  * for the single detection layer of models/model.yaml: loss values and d(loss * batch) / d pred in one call.
  * pred f32 (B, na, ny, nx, 5+nc) contiguous; targets f32 (nt, 6) = (image, class, x, y, w, h) normalised (device);

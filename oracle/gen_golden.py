@@ -201,6 +201,9 @@ def full_model_goldens(ref_model, out):
     loss = pred[0].float().square().mean()
     loss.backward()
     gnorm = {k: float(p.grad.double().norm()) for k, p in m.named_parameters()}
+    # sub-sampled gradient VALUES of the reference (a permuted or sign-flipped gradient of equal norm must not pass): up to
+    # 64 elements per parameter at a stride that covers the whole tensor
+    gsub = {k: p.grad.detach().reshape(-1)[::max(1, p.numel() // 64)][:64].clone() for k, p in m.named_parameters()}
     stats_after = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}
 
     osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "anchor" not in k)
@@ -237,7 +240,7 @@ def full_model_goldens(ref_model, out):
         logits_sub=pred[0].detach()[:, :, ::8, ::8, :].contiguous(),
         feats_sub=[sub(f.detach(), 8) for f in feats[:3]],
         taps_sub={k: v.detach().view(1, -1, v.shape[-1])[:, ::97, ::7].contiguous() for k, v in taps.items()},
-        loss=float(loss), gnorm=gnorm,
+        loss=float(loss), gnorm=gnorm, gsub=gsub,
         stats_after_sub={k: v[::8].clone() for k, v in stats_after.items()},
         z_sub=z[:, ::257, :].contiguous(),
     )

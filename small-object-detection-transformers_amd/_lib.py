@@ -103,6 +103,7 @@ SIGNATURES = {
     "sodt_yolo_loss": [_P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _P, C.c_size_t, _P, _P, _P],
     "sodt_sgd_ema_step": [_P, _P, _P, _P, _P, _I, _P, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                           _I, _F, _F, _P],
+    "sodt_preprocess_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "sodt_debug_wmsa_stamps": [_P, _I],
     "sodt_debug_wmsa_hg_stamps": [_P, _I],
 }

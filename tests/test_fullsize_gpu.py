@@ -26,6 +26,40 @@ def test_fullsize_f32_logits_vs_oracle(dev):
     assert e <= 1e-3, f"1024^2 f32 logits vs oracle: {e:.3e} (|logit| max {s:.2f})"
 
 
+def test_fullsize_f32_gradients_vs_oracle(dev):
+    """B = 1 @1024^2, f32: the hand-written backward against the oracle's autograd ELEMENTWISE for parameters spread over the
+    front end, every stage (incl. a relative-position bias table and LayerNorm weights), both PatchMergings, a neck and the
+    head; <= 2e-3 of the gradient's largest element."""
+    from oracle import ref_torch as R
+    torch.set_num_threads(16)
+    model, sd = build(dev, 1024)
+    model.compute_dtype = torch.float32
+    model.train()
+    x_rgb, x_ir = R.synthetic_inputs(1, 1024, seed=5)
+    pred, _ = model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
+    gsel = R._hash01("gsel1024", pred[0].numel()).view(pred[0].shape).float()
+    (pred[0] * gsel.to(dev)).sum().backward()
+    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "anchor" not in k) for k, v in sd.items()}
+    opred, _ = R.model_forward(osd, x_rgb, x_ir, True, {})
+    (opred[0] * gsel).sum().backward()
+    E = "image_encoder."
+    names = [E + "channel_embed_r.proj.weight", E + "chan_block.norm2.weight", E + "patch_embed.proj.weight",
+             E + "stage1.0.attn.qkv.weight", E + "stage1.1.attn.relative_position_bias_table", E + "stage1.1.mlp.conv1.weight",
+             E + "stage1.3.norm1.weight", E + "stage1.5.attn.proj.bias", E + "stage1.4.mlp.fc1.weight", E + "pmerging1.reduction.weight",
+             E + "stage2.0.norm2.weight", E + "stage2.1.attn.qkv.bias", E + "stage2.3.mlp.fc2.weight", E + "pmerging2.norm.weight",
+             E + "stage3.0.attn.relative_position_bias_table", E + "stage3.0.attn.proj.weight", E + "neck1.weight",
+             "detect.3.m.0.cv2.conv.weight", "detect.7.cv3.bn.weight", "detect.8.m.0.weight"]
+    params = dict(model.named_parameters())
+    worst = ("", 0.0)
+    for n in names:
+        ref = osd[n].grad.double()
+        got = params[n].grad.double().cpu()
+        r = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        if r > worst[1]:
+            worst = (n, r)
+    assert worst[1] <= 2e-3, f"1024^2 f32 gradient vs oracle autograd: {worst}"
+
+
 def test_batch_of_8_is_8_independent_images_bf16(dev):
     from oracle import ref_torch as R
     model, _ = build(dev, 1024)

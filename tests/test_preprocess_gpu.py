@@ -1,0 +1,41 @@
+"""sodt_preprocess_u8 (csrc/preprocess.hip) against the calls the reference's loop makes (Train.py:364-374):
+``x.float() / 255.0`` then ``F.interpolate(x, size=[i // down_factor ...], mode='bilinear', align_corners=True)``, computed
+here with the same torch functions on the CPU; within 1e-6 (f32 rounding of the four-tap blend), incl. odd sizes, a
+non-multiple-of-4 output width, down_factor 1 / 2 / 4, and the model consuming the result."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+PKG = "small-object-detection-transformers_amd"
+
+
+def _ref(x_u8, f):
+    x = x_u8.float() / 255.0
+    if f > 1:
+        x = F.interpolate(x, size=[i // f for i in x.shape[2:]], mode="bilinear", align_corners=True)
+    return x
+
+
+@pytest.mark.parametrize("B,H,W,f", [(2, 64, 64, 2), (1, 1024, 1024, 2), (2, 100, 74, 2), (1, 96, 120, 4), (3, 48, 50, 1), (1, 37, 29, 3)])
+def test_preprocess_matches_torch(dev, B, H, W, f):
+    P = importlib.import_module(PKG + ".preprocess")
+    g = torch.Generator().manual_seed(B * 1000 + H + f)
+    rgb = torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8)
+    ir = torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8)
+    o1, o2 = P.preprocess_batch(rgb.to(dev), ir.to(dev), f)
+    torch.cuda.synchronize()
+    r1, r2 = _ref(rgb, f), _ref(ir, f)
+    assert o1.shape == r1.shape and o2.shape == r2.shape and o1.dtype == torch.float32
+    assert float((o1.cpu() - r1).abs().max()) <= 1e-6 and float((o2.cpu() - r2).abs().max()) <= 1e-6
+
+
+def test_preprocess_rejects_cpu_and_float_inputs(dev):
+    P = importlib.import_module(PKG + ".preprocess")
+    x = torch.zeros(1, 3, 8, 8, dtype=torch.uint8)
+    with pytest.raises(RuntimeError):
+        P.preprocess_batch(x, x, 2)
+    with pytest.raises(TypeError):
+        P.preprocess_batch(x.float().to(dev), x.float().to(dev), 2)
