@@ -4,9 +4,13 @@
 //     imgs  = F.interpolate(image, size=[i // down_factor ...], mode='bilinear', align_corners=True)   Train.py:371-374
 //
 // for the RGB and the IR batch in ONE launch: uint8 planes in, f32 planes out (the layout the front-end kernel reads).
-// Bilinear with align_corners=True as ATen computes it: src = dst * (in - 1) / (out - 1) in f32, i0 = (int)src clamped,
-// l1 = src - i0, i1 = min(i0 + 1, in - 1), value = (1-ly)((1-lx) p00 + lx p01) + ly((1-lx) p10 + lx p11).  out == in is
-// the identity (scale 1): plain u8 -> f32 / 255.
+// Bilinear with align_corners=True: src = dst * (in - 1) / (out - 1), i0 = floor(src), l1 = src - i0, i1 = min(i0 + 1, in - 1),
+// value = (1-ly)((1-lx) p00 + lx p01) + ly((1-lx) p10 + lx p11).  ATen evaluates src in f32 (scale = (in-1)/(out-1) rounded,
+// then a product that its AVX2 / AVX-512 builds may or may not contract with the subtraction): its own l1 moves by up to an
+// ulp of the COORDINATE between machines (6e-5 at 1024 pixels).  Here i0 and l1 come from the exact integer quotient and
+// remainder of dst * (in - 1) by (out - 1) - one rounding, in the final division - so the result is the correctly rounded
+// evaluation of the same formula: within 1e-6 of the float64 evaluation, and inside ATen-f32's own coordinate noise.
+// out == in is the identity: plain u8 -> f32 / 255.
 //
 // HBM-bound byte work (6 MB in, 6.3 MB out per 1024^2 image pair at down_factor 2): one thread produces four consecutive
 // output pixels of one plane (one 16-byte store); its 2 x (up to 10) source bytes are two rows of one cache line region,
@@ -20,7 +24,6 @@ struct PreArgs {
   const unsigned char* src[2]; float* dst[2];
   int planes[2];              // B * channels of the RGB / IR tensor
   int Hin, Win, Hout, Wout;
-  float sy, sx;               // (in - 1) / (out - 1), 0 when out == 1
 };
 
 __global__ __launch_bounds__(256) void preprocess_u8_kernel(const PreArgs a) {
@@ -35,10 +38,9 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const PreArgs a) {
     if (which) pl -= a.planes[0];
     const unsigned char* sp = a.src[which] + pl * (long)a.Hin * a.Win;
     float* dp = a.dst[which] + pl * (long)a.Hout * a.Wout + (long)oy * a.Wout + ox0;
-    const float fy = a.sy * (float)oy;
-    int y0 = (int)fy;
-    y0 = y0 < a.Hin - 1 ? y0 : a.Hin - 1;
-    const float ly = fminf(fmaxf(fy - (float)y0, 0.f), 1.f);
+    const int dy = a.Hout > 1 ? a.Hout - 1 : 1, ny = a.Hout > 1 ? oy * (a.Hin - 1) : 0;      // src = ny / dy exactly
+    const int y0 = ny / dy;
+    const float ly = (float)(ny - y0 * dy) / (float)dy;
     const int y1 = y0 + 1 < a.Hin ? y0 + 1 : a.Hin - 1;
     const unsigned char* r0 = sp + (long)y0 * a.Win;
     const unsigned char* r1 = sp + (long)y1 * a.Win;
@@ -46,10 +48,9 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const PreArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ox = ox0 + i < a.Wout ? ox0 + i : a.Wout - 1;
-      const float fx = a.sx * (float)ox;
-      int x0 = (int)fx;
-      x0 = x0 < a.Win - 1 ? x0 : a.Win - 1;
-      const float lx = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+      const int dx = a.Wout > 1 ? a.Wout - 1 : 1, nx = a.Wout > 1 ? ox * (a.Win - 1) : 0;
+      const int x0 = nx / dx;
+      const float lx = (float)(nx - x0 * dx) / (float)dx;
       const int x1 = x0 + 1 < a.Win ? x0 + 1 : a.Win - 1;
       const float p00 = (float)r0[x0] / 255.0f, p01 = (float)r0[x1] / 255.0f;
       const float p10 = (float)r1[x0] / 255.0f, p11 = (float)r1[x1] / 255.0f;
@@ -75,8 +76,7 @@ extern "C" int sodt_preprocess_u8(const unsigned char* rgb, const unsigned char*
   a.src[0] = rgb; a.src[1] = ir; a.dst[0] = out_rgb; a.dst[1] = out_ir;
   a.planes[0] = B * c_rgb; a.planes[1] = B * c_ir;
   a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
-  a.sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
-  a.sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+  if ((long)Hin * Hout >= (1L << 31) || (long)Win * Wout >= (1L << 31)) return SODT_EINVAL;
   const long total = (long)Hout * ((Wout + 3) / 4) * (a.planes[0] + a.planes[1]);
   long blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
