@@ -41,6 +41,14 @@ constexpr int HG_LDS_INF = HG_VP_OFF, HG_LDS_SAVE = HG_VP_OFF + 8 * 1024;
 static_assert(HG_LDS_SAVE <= 160 * 1024, "LDS budget");
 static_assert(WL<bf16>::STAGE == 24576 && WL<bf16>::BIAS_OFF == HG_HEADW && WL<bf16>::BQKV_OFF == HG_HEADW + 1920, "pack layout");
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_;
+// a - b on two f32 lanes in one VALU slot (hipcc scalarises a vector subtraction whose results feed v_exp_f32)
+__device__ __forceinline__ f32x2_ pk_sub(const f32x2_& a, const f32x2_& b) {
+  f32x2_ r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // STAMP: diagnostic build (sodt_debug_wmsa_hg_stamps): wave 0 of every workgroup sums shader cycles per phase
 __device__ long long g_hg_stamps[512][12];     // rows 0..255: wave 0 (window A, older), 256..511: wave 4 (window B, same SIMD)
 __device__ __forceinline__ long long hg_now() {
@@ -320,13 +328,18 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
               mx = fmaxf(mx, s[ks][r]);
             }
           mx = rows_max(mx);
-          float sum = 0.f;
+          // (vector forms: hipcc turns the subtraction and the running sums into v_pk_add_f32, two elements per VALU slot -
+          //  the SIMD issues one wave64 f32 instruction per 4 cycles whatever the number of waves)
+          f32x4 sum4 = f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x2_ mx2 = f32x2_{mx, mx};
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(s[ks][r] - mx); s[ks][r] = p; sum += p; }
+            const f32x2_ d0 = pk_sub(f32x2_{s[ks][0], s[ks][1]}, mx2), d1 = pk_sub(f32x2_{s[ks][2], s[ks][3]}, mx2);
+            s[ks] = f32x4{__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1]), __builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
+            sum4 += s[ks];
             pp[ks][ms] = pk16<T>(s[ks]);
           }
+          float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
           sum = rows_sum(sum);
           inv[ms] = __builtin_amdgcn_rcpf(sum);
           if (ms < 3) dma_part(step + 1, 3 + 2 * ms, 5 + 2 * ms);
