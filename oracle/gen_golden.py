@@ -415,6 +415,57 @@ def loss_goldens(out):
     print("[pin] wrote loss.pt")
 
 
+SPP_HEAD = [[2, 1, "Conv", [512, 1, 1]], [-1, 1, "SPP", [512, [5, 9, 13]]], [-1, 1, "nn.Upsample", [None, 2, "nearest"]],
+            [[-1, 1], 1, "Concat", [1]], [-1, 3, "C3", [512, False]], [-1, 1, "Conv", [256, 1, 1]],
+            [-1, 1, "nn.Upsample", [None, 2, "nearest"]], [[-1, 0], 1, "Concat", [1]], [-1, 3, "C3", [256, False]],
+            [[11], 1, "Detect", ["nc", "anchors"]]]
+
+
+def spp_head_goldens(ref_model, out):
+    """A head yaml with an SPP row (common.py:129-140; the row SRyolo_MF.yaml:46 uses) after detect.0: the reference's own
+    parse_model / forward_once build and run it (model.py:350-435, :268-281).  Pins the oracle's generic head walk
+    (ref_torch.head_graph) against the real reference at 512^2 and stores sub-sampled logits, the loss, gradient norms and
+    sub-sampled gradient values.  Weights: ref_torch.procedural_from_shapes over the reference model's own float
+    state_dict shapes (reproducible on the GPU box from the build's Model with the same cfg)."""
+    import yaml
+    Model = ref_model.Model
+    cfg = yaml.safe_load(open("/root/reference/models/model.yaml"))
+    cfg["head"] = [list(r) for r in SPP_HEAD]
+    m = Model(cfg, input_mode="RGB+IR", ch_steam=3, ch=128, nc=8)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()
+              if v.dtype.is_floating_point and not k.endswith("attn_mask")}
+    sd = R.procedural_from_shapes(shapes)
+    with torch.no_grad():
+        load_into(m, sd)
+    x_rgb, x_ir = R.synthetic_inputs(1, 512, seed=9)
+    m.train()
+    pred, feats = m(x_rgb, x_ir, "RGB+IR")
+    loss = pred[0].float().square().mean()
+    loss.backward()
+    gnorm = {k: float(p.grad.double().norm()) for k, p in m.named_parameters()}
+    gsub = {k: p.grad.detach().reshape(-1)[::max(1, p.numel() // 64)][:64].clone() for k, p in m.named_parameters()
+            if k.startswith("detect.") or "neck" in k or "stage3.0.attn.qkv" in k}
+    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "anchor" not in k) for k, v in sd.items()}
+    opred, ofeats = R.model_forward(osd, x_rgb, x_ir, True, {}, head_rows=SPP_HEAD)
+    opred[0].square().mean().backward()
+    d = maxdiff(pred[0], opred[0])
+    dgn = max((abs(gnorm[k] - float(osd[k].grad.double().norm())) - 1e-7) / (gnorm[k] + 1e-12) for k in gnorm)
+    print(f"[pin] SPP head @512^2: logits maxdiff {d:.3e} (|logit| max {float(pred[0].abs().max()):.2f}); y[4] (SPP out) "
+          f"{maxdiff(feats[4], ofeats[4]):.3e}; grad-norm rel diff {dgn:.3e}")
+    assert d < 1e-4 and dgn < 1e-4 and maxdiff(feats[4], ofeats[4]) < 1e-4
+    # the model.yaml head through the generic walk equals the hard-wired statement
+    rows0 = yaml.safe_load(open("/root/reference/models/model.yaml"))["head"]
+    sd0 = R.procedural_state_dict(128, 8)
+    a0, b0 = R.synthetic_inputs(1, 128, seed=2)
+    p1, _ = R.model_forward(sd0, a0, b0, True, {})
+    p2, _ = R.model_forward(sd0, a0, b0, True, {}, head_rows=rows0)
+    assert torch.equal(p1[0], p2[0])
+    torch.save(dict(img_size=512, seed=9, head=SPP_HEAD, logits_sub=pred[0].detach()[:, :, ::8, ::8, :].contiguous(),
+                    spp_out_sub=sub(feats[4].detach(), 4), loss=float(loss), gnorm=gnorm, gsub=gsub,
+                    nkeys=len(shapes)), os.path.join(out, "spp_head_512.pt"))
+    print("[pin] wrote spp_head_512.pt")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -422,6 +473,7 @@ def main():
     ap.add_argument("--only-loss", action="store_true")
     ap.add_argument("--only-autocast", action="store_true")
     ap.add_argument("--only-spp", action="store_true")
+    ap.add_argument("--only-spp-head", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
@@ -435,6 +487,9 @@ def main():
     if a.only_spp:
         spp_goldens(ref_common, GOLD)
         return
+    if a.only_spp_head:
+        spp_head_goldens(ref_model, GOLD)
+        return
     loss_goldens(GOLD)
     nms_goldens(GOLD)
     if a.only_nms:
@@ -444,6 +499,7 @@ def main():
     if not a.skip_full:
         full_model_goldens(ref_model, GOLD)
         autocast_goldens(ref_model, GOLD)
+        spp_head_goldens(ref_model, GOLD)
 
 
 if __name__ == "__main__":

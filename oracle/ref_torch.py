@@ -366,16 +366,56 @@ def head(sd: SD, feats: Sequence[Tensor], training: bool, new_stats: Optional[di
     return raw, y
 
 
+def head_graph(sd: SD, feats: Sequence[Tensor], rows, training: bool, new_stats: Optional[dict] = None,
+               pfx: str = "detect.") -> Tuple[Tensor, List[Tensor]]:
+    """Any head yaml (rows of [from, number, module, args], models/model.yaml:65-74) run as Model.forward_once runs the
+    nn.Sequential parse_model built from it (model.py:268-281): the input of row i is y[f] (f = -1: the previous row), or
+    the list of them; y[0..2] are the encoder outputs and row i appends y[3 + i].  Modules: Conv, C3, SPP, nn.Upsample,
+    Concat, Detect (common.py:38-140,275-282; model.py:48-55)."""
+    y = list(feats)
+    x = None
+    raw = None
+    for i, (f, _n, m, _args) in enumerate(rows):
+        if isinstance(f, int):
+            xin = x if f == -1 else y[f]
+        else:
+            xin = [x if j == -1 else y[j] for j in f]
+        p = f"{pfx}{i}."
+        if m == "Conv":
+            x = conv_bn_silu(sd, p, xin, training, new_stats)
+        elif m == "C3":
+            x = c3(sd, p, xin, training, new_stats)
+        elif m == "SPP":
+            x = spp(sd, p, xin, training, new_stats)
+        elif m == "nn.Upsample":
+            x = F.interpolate(xin, scale_factor=2, mode="nearest")
+        elif m == "Concat":
+            x = torch.cat(xin, 1)
+        elif m == "Detect":
+            raw = detect_raw(sd, p, xin[0])
+            break
+        else:
+            raise NotImplementedError(m)
+        y.append(x)
+    return raw, y
+
+
 def model_forward(sd: SD, x_rgb: Tensor, x_ir: Tensor, training: bool = True,
-                  new_stats: Optional[dict] = None, taps: Optional[dict] = None, ca_window: int = 1, ca_shift: int = 0):
+                  new_stats: Optional[dict] = None, taps: Optional[dict] = None, ca_window: int = 1, ca_shift: int = 0,
+                  head_rows=None):
     """Model.forward, input_mode='RGB+IR' (model.py:191-192, :207-211, :245-294).
-    train -> ([raw], y) ; eval -> (z, [raw], y)."""
+    train -> ([raw], y) ; eval -> (z, [raw], y).  head_rows: a head yaml other than models/model.yaml:65-74 (head_graph)."""
     x4 = torch.cat([x_rgb, x_ir[:, 0:1]], 1)
     feats = image_encoder(sd, x4, taps=taps, ca_window=ca_window, ca_shift=ca_shift)
-    raw, y = head(sd, feats, training, new_stats)
+    if head_rows is None:
+        raw, y = head(sd, feats, training, new_stats)
+        det = "detect.8."
+    else:
+        raw, y = head_graph(sd, feats, head_rows, training, new_stats)
+        det = f"detect.{len(head_rows) - 1}."
     if training:
         return [raw], y + [[raw]]
-    z = detect_decode(raw, sd["detect.8.anchor_grid"])
+    z = detect_decode(raw, sd[det + "anchor_grid"])
     return z, [raw], y + [(z, [raw])]
 
 
@@ -706,8 +746,15 @@ def procedural_state_dict(img_size: int = 512, nc: int = 8, dtype=torch.float32)
     """Procedural weights: same statistics class as the reference's default init
     (uniform(-1/sqrt(fan_in), +)) so activations stay O(1) through 11 blocks, but
     every value is a closed-form function of (name, index)."""
+    return procedural_from_shapes(state_dict_spec(img_size, nc), dtype)
+
+
+def procedural_from_shapes(shapes: Dict[str, Tuple[int, ...]], dtype=torch.float32) -> SD:
+    """The same closed-form weights for ANY name -> shape table (e.g. the float entries of a model's own state_dict, for
+    head graphs other than models/model.yaml)."""
     sd: SD = {}
-    for name, shape in state_dict_spec(img_size, nc).items():
+    for name, shape in shapes.items():
+        shape = tuple(shape)
         n = 1
         for d in shape:
             n *= d

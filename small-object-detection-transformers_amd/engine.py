@@ -80,18 +80,21 @@ class Plan:
 
 
 class _LazyFeatures(list):
-    """forward_once's feature list `y` (model.py:268-281).  Entries 4, 5, 8, 9 - nn.Upsample(x2, nearest) of y[3] / y[7]
-    and their Concat with y[1] / y[0] (models/model.yaml:66-67,71-72) - are index arithmetic inside the GEMM loaders
-    and never exist in the workspace; they are computed on first access."""
-    _RULES = {4: ("up", 3), 8: ("up", 7), 5: ("cat", 4, 1), 9: ("cat", 8, 0)}
+    """forward_once's feature list `y` (model.py:268-281).  Entries produced by nn.Upsample(x2, nearest) and Concat
+    (models/model.yaml:66-67,71-72: y[4], y[5], y[8], y[9]) are index arithmetic inside the GEMM loaders and never exist in
+    the workspace; they are computed on first access.  rules: {index: ("up", src) | ("cat", [srcs])} from the head plan."""
+
+    def __init__(self, items=(), rules=None):
+        super().__init__(items)
+        self._rules = dict(rules or {})
 
     def _fill(self, i):
-        if list.__getitem__(self, i) is None and i in self._RULES:
-            r = self._RULES[i]
+        if list.__getitem__(self, i) is None and i in self._rules:
+            r = self._rules[i]
             if r[0] == "up":
                 v = torch.nn.functional.interpolate(self[r[1]].float(), scale_factor=2, mode="nearest")
             else:
-                v = torch.cat((self[r[1]], self[r[2]].float()), 1)
+                v = torch.cat([self[j].float() for j in r[1]], 1)
             list.__setitem__(self, i, v)
 
     def __getitem__(self, i):
@@ -99,17 +102,17 @@ class _LazyFeatures(list):
             j = i + len(self) if i < 0 else i
             self._fill(j)
         else:
-            for j in self._RULES:
+            for j in sorted(self._rules):
                 self._fill(j)
         return list.__getitem__(self, i)
 
     def __iter__(self):
-        for j in self._RULES:
+        for j in sorted(self._rules):
             self._fill(j)
         return list.__iter__(self)
 
     def __add__(self, other):       # Model.forward appends the head output: stay lazy
-        out = _LazyFeatures(list.__iter__(self))
+        out = _LazyFeatures(list.__iter__(self), self._rules)
         list.extend(out, other)
         return out
 
@@ -152,7 +155,7 @@ class Engine:
         self.img_t = enc.pos_embed.shape[1]
         det = model.detect[-1]
         self.na, self.no, self.nc = det.na, det.no, det.nc
-        self.fused = not hasattr(model.detect[0], "bn")
+        self.fused = not any(type(m).__name__ == "BatchNorm2d" for m in model.detect.modules())
         self._check_head()
         self.plans: Dict[Tuple, Plan] = {}
         self.probes_fwd: Optional[dict] = None    # bench.py: {call index: (start event, end event)}
@@ -168,20 +171,88 @@ class Engine:
         self._tn_scratch = torch.empty(16 << 20, dtype=torch.float32, device=self.dev)
         ops.set_tn_scratch(self._tn_scratch)
 
-    # ------------------------------------------------------------------ structure checks
+    # ------------------------------------------------------------------ head graph
     def _check_head(self):
+        """Parse ``model.detect`` (parse_model's nn.Sequential with the reference's ``.f`` wiring, model.py:268-281) into a
+        launch plan.  Accepted: any CHAIN of compute units - Conv (1x1 or 3x3, stride 1), C3 (n = 1), SPP - in which every
+        unit reads ONE feature-list entry, possibly through nn.Upsample(x2, nearest) and Concat rows (their inputs: the
+        previous rows or encoder outputs y[0..2]), ending in a one-layer Detect; every unit output and every encoder output
+        is consumed exactly once.  That covers models/model.yaml:65-74, the identical head of SRyolo_MF.yaml:52-71, and
+        variants with extra Conv / SPP (common.py:129-140) rows.  Upsample and Concat never move data: they become the
+        K-segments (source + spatial map) of the consuming unit's first GEMM."""
         from . import model as M
-        kinds = [type(m).__name__ for m in self.model.detect]
-        want = ["Conv", "Upsample", "Concat", "C3", "Conv", "Upsample", "Concat", "C3", "Detect"]
-        if kinds != want:
-            raise NotImplementedError(f"head graph {kinds} is not models/model.yaml:65-74 ({want})")
         d = self.model.detect
-        if d[2].f != [-1, 1] or d[6].f != [-1, 0] or d[0].f != 2 or d[8].f != [10]:
-            raise NotImplementedError("head wiring differs from models/model.yaml:65-74")
-        for c3 in (d[3], d[7]):
-            if len(c3.m) != 1 or c3.m[0].add:
-                raise NotImplementedError("C3 with n=1, shortcut=False only (models/model.yaml:68,73)")
-        assert isinstance(d[8], M.Detect) and d[8].nl == 1
+        enc_c = (256, 256, 512)                                   # neck widths (backbone_vit.py:167-187), levels 0, 1, 2
+        # virtual tensor: (parts, level) with parts = [(ref, C, shr)], ref = ("enc", j) | ("unit", k); resolution t >> level
+        vals = {j: ([(("enc", j), enc_c[j], 0)], j) for j in range(3)}
+        units, rules = [], {}
+        uses: Dict[tuple, int] = {}
+
+        def resolve(f, yi):
+            j = yi - 1 if f == -1 else f
+            if not isinstance(j, int) or j not in vals or j >= yi:
+                raise NotImplementedError(f"head row {yi - 3}: input {f!r} does not name an earlier feature-list entry")
+            return j
+        if not isinstance(d[-1], M.Detect) or d[-1].nl != 1:
+            raise NotImplementedError("the head must end in a one-layer Detect (models/model.yaml:74)")
+        for k, m in enumerate(d):
+            yi, kind = 3 + k, type(m).__name__
+            if kind in ("Conv", "C3", "SPP"):
+                if not isinstance(m.f, int):
+                    raise NotImplementedError(f"head row {k}: {kind} takes one input")
+                parts, level = vals[resolve(m.f, yi)]
+                c1 = sum(c for _, c, _ in parts)
+                if kind == "Conv":
+                    kk, c2 = m.conv.kernel_size[0], m.conv.out_channels
+                    if m.conv.in_channels != c1:
+                        raise NotImplementedError(f"head row {k}: Conv expects {m.conv.in_channels} channels, graph gives {c1}")
+                    if kk == 3 and len(parts) * 9 > L.MAX_SEG:
+                        raise NotImplementedError(f"head row {k}: a 3x3 Conv on a concatenation needs {len(parts) * 9} K-segments (max {L.MAX_SEG})")
+                elif kind == "C3":
+                    kk, c2 = 1, m.cv3.conv.out_channels
+                    if len(m.m) != 1 or m.m[0].add:
+                        raise NotImplementedError("C3 with n=1, shortcut=False only (models/model.yaml:68,73)")
+                    if m.cv1.conv.in_channels != c1:
+                        raise NotImplementedError(f"head row {k}: C3 expects {m.cv1.conv.in_channels} channels, graph gives {c1}")
+                else:
+                    kk, c2 = 1, m.cv2.conv.out_channels
+                    if m.cv1.conv.in_channels != c1:
+                        raise NotImplementedError(f"head row {k}: SPP expects {m.cv1.conv.in_channels} channels, graph gives {c1}")
+                for ref, _, _ in parts:
+                    uses[ref] = uses.get(ref, 0) + 1
+                units.append(dict(k=k, kind=kind, parts=parts, level=level, c1=c1, c2=c2, ksize=kk))
+                vals[yi] = ([(("unit", k), c2, 0)], level)
+            elif kind == "Upsample":
+                parts, level = vals[resolve(m.f, yi)]
+                if level == 0:
+                    raise NotImplementedError(f"head row {k}: Upsample above the stride-4 grid of Detect (model.py:130)")
+                vals[yi] = ([(ref, c, shr + 1) for ref, c, shr in parts], level - 1)
+                rules[yi] = ("up", resolve(m.f, yi))
+            elif kind == "Concat":
+                srcs = [resolve(f, yi) for f in m.f]
+                if len({vals[j][1] for j in srcs}) != 1:
+                    raise NotImplementedError(f"head row {k}: Concat of different resolutions")
+                vals[yi] = (sum((vals[j][0] for j in srcs), []), vals[srcs[0]][1])
+                rules[yi] = ("cat", srcs)
+            elif kind == "Detect":
+                if k != len(d) - 1 or len(m.f) != 1:
+                    raise NotImplementedError("Detect must be the last row with one input")
+                parts, level = vals[resolve(m.f[0], yi)]
+                if len(parts) != 1 or parts[0][0][0] != "unit" or parts[0][2] != 0 or level != 0:
+                    raise NotImplementedError("Detect reads one unit output on the stride-4 grid (model.py:130: stride = [4.])")
+                uses[parts[0][0]] = uses.get(parts[0][0], 0) + 1
+                self.head_out = (parts[0][0][1], parts[0][1])          # (unit row, channels)
+            else:
+                raise NotImplementedError(f"head row {k}: module {kind} is outside the hot path (SURVEY.md section 8)")
+        for ref in [("enc", j) for j in range(3)] + [("unit", u["k"]) for u in units]:
+            if uses.get(ref, 0) != 1:
+                raise NotImplementedError(f"head: {ref} is consumed {uses.get(ref, 0)} times; the hand-written backward routes every "
+                                          "feature to exactly one consumer")
+        self.head_units, self.head_rules, self.nd = units, rules, len(d) - 1
+        self.det_name = f"detect.{self.nd}."
+
+    def _unit_out_name(self, u):
+        return f"h{u['k']}" + {"Conv": ".y", "C3": ".cv3.y", "SPP": ".cv2.y"}[u["kind"]]
 
     # ------------------------------------------------------------------ gradients: one flat f32 buffer
     def _build_grad_buffer(self):
@@ -314,7 +385,7 @@ class Engine:
                 continue
             N, K = p.shape[0], p.shape[1]
             taps = p.numel() // (N * K)
-            Np = (N + 15) // 16 * 16 if n.startswith("detect.8.") else N     # Detect: 39 -> 48 zero-padded
+            Np = (N + 15) // 16 * 16 if n.startswith(self.det_name) else N     # Detect: 39 -> 48 zero-padded
             if taps == 1 and Np == N:
                 w[n] = mview(n, (N, K))
             else:
@@ -410,7 +481,7 @@ class Engine:
     def decode(self, pred):
         B, na, ny, nx, no = pred.shape
         z = torch.empty(B, na * ny * nx, no, device=pred.device, dtype=torch.float32)
-        ag = self.buffers["detect.8.anchor_grid"].reshape(-1).contiguous().float()
+        ag = self.buffers[self.det_name + "anchor_grid"].reshape(-1).contiguous().float()
         ops.detect_decode(pred, ag, z, B, na, ny, nx, no, 4.0)
         return z
 
@@ -424,11 +495,12 @@ class Engine:
 
         def nchw(name, h, c):
             return b[name].view(B, h, h, c).permute(0, 3, 1, 2)
-        y = _LazyFeatures([nchw("f0", t, 256), nchw("f1", t // 2, 256), nchw("f2", t // 4, 512), nchw("h0.y", t // 4, 256),
-                           None, None, nchw("h3.cv3.y", t // 2, 256), nchw("h4.y", t // 2, 128), None, None,
-                           nchw("h7.cv3.y", t, 128)])
+        items = [nchw("f0", t, 256), nchw("f1", t // 2, 256), nchw("f2", t // 4, 512)] + [None] * self.nd
+        for u in self.head_units:
+            items[3 + u["k"]] = nchw(self._unit_out_name(u), t >> u["level"], u["c2"])
+        y = _LazyFeatures(items, self.head_rules)
         if self.model.materialize_features:
-            for i in (4, 5, 8, 9):
+            for i in sorted(self.head_rules):
                 y[i]
         return y
 
@@ -474,8 +546,9 @@ class Engine:
         # (4) Detect: live (fresh output tensor every call)
         T1 = B * t * t
         pred = torch.empty(B, self.na, t, t, self.no, device=self.dev, dtype=torch.float32)
-        ops.gemm_nt([SegSpec(plan.bufs["h7.cv3.y"])], P["w"]["detect.8.m.0.weight"], pred, T1, self.na * self.no, 128,
-                    bias=self.params["detect.8.m.0.bias"], detect=(self.na, self.no, t * t))
+        hu = next(u for u in self.head_units if u["k"] == self.head_out[0])
+        ops.gemm_nt([SegSpec(plan.bufs[self._unit_out_name(hu)])], P["w"][self.det_name + "m.0.weight"], pred, T1, self.na * self.no,
+                    self.head_out[1], bias=self.params[self.det_name + "m.0.bias"], detect=(self.na, self.no, t * t))
         return pred
 
     def _replay(self, plan: Plan, key: str, calls, probes):
@@ -534,14 +607,32 @@ class Engine:
         T3 = B * H * H
         f2 = plan.buf("f2", (T3, 512))
         ops.gemm_nt([SegSpec(x)], w[E + "neck3.weight"], f2, T3, 512, 768)
-        # ---- head (models/model.yaml:65-74), token-major
-        h4, h2 = t // 4, t // 2
-        y3 = self._conv_fwd(plan, P, "h0", "detect.0.", [SegSpec(f2)], None, T3, 512, 256, 1)
-        segs = [SegSpec(y3, 256, 0, 0, 0, 1, 1, h4, h4), SegSpec(f1, 256, 0, 0, 0, 1, 0, h2, h2)]
-        y6 = self._c3_fwd(plan, P, "h3", "detect.3.", segs, (h2, h2), T2, 512, 256)
-        y7 = self._conv_fwd(plan, P, "h4", "detect.4.", [SegSpec(y6)], None, T2, 256, 128, 1)
-        segs = [SegSpec(y7, 128, 0, 0, 0, 1, 1, h2, h2), SegSpec(f0, 256, 0, 0, 0, 1, 0, t, t)]
-        self._c3_fwd(plan, P, "h7", "detect.7.", segs, (t, t), T1, 384, 128)
+        # ---- head (models/model.yaml:65-74 and the variants _check_head accepts), token-major
+        self._head_fwd(plan, P)
+
+    def _head_fwd(self, plan: Plan, P):
+        B, t = plan.B, plan.S // 4
+        b = plan.bufs
+        for u in self.head_units:
+            H = t >> u["level"]
+            M = B * H * H
+            tag, pname = f"h{u['k']}", f"detect.{u['k']}."
+            plain = all(shr == 0 for _, _, shr in u["parts"]) and ((u["kind"] == "Conv" and u["ksize"] == 1) or u["kind"] == "SPP")
+            segs = []
+            for ref, c, shr in u["parts"]:
+                src = b[("f0", "f1", "f2")[ref[1]]] if ref[0] == "enc" else b[self._unit_out_name(self._unit(ref[1]))]
+                segs.append(SegSpec(src) if plain else SegSpec(src, c, 0, 0, 0, 1, shr, H >> shr, H >> shr))
+            if u["kind"] == "Conv":
+                if u["ksize"] == 3:
+                    segs = [SegSpec(s_.t, s_.klen, 0, dy, dx, 1, s_.shr, s_.Hi, s_.Wi) for (dy, dx) in TAPS3 for s_ in segs]
+                self._conv_fwd(plan, P, tag, pname, segs, None if plain else (H, H), M, u["c1"] * u["ksize"] ** 2, u["c2"], u["ksize"])
+            elif u["kind"] == "C3":
+                self._c3_fwd(plan, P, tag, pname, segs, (H, H), M, u["c1"], u["c2"])
+            else:
+                self._spp_fwd(plan, P, tag, pname, segs, (H, H), M, u["c1"], u["c2"], B)
+
+    def _unit(self, k):
+        return next(u for u in self.head_units if u["k"] == k)
 
     # ------------------------------------------------------------------ Swin block
     def _block_geo(self, blk, H, W):
@@ -695,28 +786,30 @@ class Engine:
                         spatial=(H // 2, W // 2), w_off=tap * Cc * 2 * Cc, oscatter=(2, dy, dx, H, W))
 
     # ------------------------------------------------------------------ head units
-    def _conv_fwd(self, plan, P, tag, pname, segs, spatial, M, K, Cout, k):
-        """Conv2d(bias=False)+BN+SiLU (common.py:38-50) as GEMM (+f64 column stats) -> finalize -> normalise+SiLU."""
+    def _conv_fwd(self, plan, P, tag, pname, segs, spatial, M, K, Cout, k, out=None):
+        """Conv2d(bias=False)+BN+SiLU (common.py:38-50) as GEMM (+f64 column stats) -> finalize -> normalise+SiLU.
+        out: write the result into the first Cout columns of this wider [M][ld] buffer (a concat slice) instead of tag.y."""
         ops.set_tag(tag)
         p, w, bufs = self.params, P["w"], self.buffers
-        y = plan.buf(tag + ".y", (M, Cout))
+        y = plan.buf(tag + ".y", (M, Cout)) if out is None else out
+        ldy = y.shape[-1]
         wname = pname + "conv.weight"
         if self.fused:
             ones = P["ones"].setdefault(Cout, torch.ones(Cout, device=self.dev))
-            ops.gemm_nt(segs, w[wname], y, M, Cout, K, spatial=spatial, affine=(ones, p[pname + "conv.bias"]))
+            ops.gemm_nt(segs, w[wname], y, M, Cout, K, spatial=spatial, affine=(ones, p[pname + "conv.bias"]), ldc=ldy)
         elif plan.training:
             z = plan.buf(tag + ".z", (M, Cout))
             stats = plan.zbuf("f", tag + ".stats", (L.STATS_REPL, 2, Cout), torch.float64)   # zeroed with the pool (_forward_main)
             mr = plan.buf(tag + ".mr", (2, Cout), torch.float32)
             ops.gemm_nt(segs, w[wname], z, M, Cout, K, spatial=spatial, stats=stats)
             ops.bn_finalize(stats, mr, bufs[pname + "bn.running_mean"], bufs[pname + "bn.running_var"], M, Cout, 1e-3, 0.03)
-            ops.bn_silu_fwd(z, mr, p[pname + "bn.weight"], p[pname + "bn.bias"], y, Cout, M, Cout)
+            ops.bn_silu_fwd(z, mr, p[pname + "bn.weight"], p[pname + "bn.bias"], y, ldy, M, Cout)
         else:
             mr = plan.buf(tag + ".mr", (2, Cout), torch.float32)
             sc = plan.buf(tag + ".sc", (2, Cout), torch.float32)
             ops.bn_finalize(None, mr, bufs[pname + "bn.running_mean"], bufs[pname + "bn.running_var"], M, Cout, 1e-3, 0.03)
             ops.bn_affine(mr, p[pname + "bn.weight"], p[pname + "bn.bias"], sc[0], sc[1], Cout)
-            ops.gemm_nt(segs, w[wname], y, M, Cout, K, spatial=spatial, affine=(sc[0], sc[1]))
+            ops.gemm_nt(segs, w[wname], y, M, Cout, K, spatial=spatial, affine=(sc[0], sc[1]), ldc=ldy)
         plan.saved[tag] = dict(segs=segs, spatial=spatial, M=M, K=K, Cout=Cout, k=k, pname=pname)
         return y
 
@@ -769,6 +862,40 @@ class Engine:
         ops.gemm_nt([SegSpec(dza2)], wT[pname + "m.0.cv1.conv.weight"], da, M, c_, c_)
         dza1 = self._conv_bwd(plan, tag + ".cv1", da, c_, 0)
         ops.gemm_nt([SegSpec(dza1)], wT[pname + "cv1.conv.weight"], din, M, c1, c_, resid=din)
+        return din
+
+    # ------------------------------------------------------------------ SPP (common.py:129-140)
+    def _spp_fwd(self, plan, P, tag, pname, segs, spatial, M, c1, c2, B):
+        """cv1 (1x1 Conv+BN+SiLU) -> MaxPool 5 / 9 / 13 (stride 1, same padding: ONE 5x5 kernel in cascade, csrc/pool.hip) ->
+        Concat -> cv2.  The concat never exists as a copy: cv1 and the pools write their slices of one [M][4 c_] buffer,
+        which is cv2's single K-segment."""
+        c_ = c1 // 2
+        H, W = spatial
+        cat = plan.buf(tag + ".cat", (M, 4 * c_))
+        self._conv_fwd(plan, P, tag + ".cv1", pname + "cv1.", segs, spatial if any(s_.shr or s_.Hi for s_ in segs) else None, M, c1, c_, 1, out=cat)
+        arg = plan.buf(tag + ".arg", (3, M, c_), torch.uint8) if plan.training else None
+        for i in range(3):                                   # m5, m9 = m5 o m5, m13 = m5 o m5 o m5 into the next slices
+            ops.maxpool5_fwd(cat, cat, arg[i] if arg is not None else None, B, H, W, c_, ldx=4 * c_, ldy=4 * c_, x_off=i * c_,
+                             y_off=(i + 1) * c_)
+        out = self._conv_fwd(plan, P, tag + ".cv2", pname + "cv2.", [SegSpec(cat)], None, M, 4 * c_, c2, 1)
+        plan.saved[tag] = dict(M=M, c1=c1, c2=c2, spatial=spatial, pname=pname, B=B)
+        return out
+
+    def _spp_bwd(self, plan, P, tag, dout, ldd, d_off):
+        """returns d(input) [M][c1]."""
+        wT, b = P["wT"], plan.bufs
+        sv = plan.saved[tag]
+        M, c1, c2, (H, W), pname, B = sv["M"], sv["c1"], sv["c2"], sv["spatial"], sv["pname"], sv["B"]
+        c_ = c1 // 2
+        dz2 = self._conv_bwd(plan, tag + ".cv2", dout, ldd, d_off)
+        dcat = plan.buf(tag + ".dcat", (M, 4 * c_))
+        ops.gemm_nt([SegSpec(dz2)], wT[pname + "cv2.conv.weight"], dcat, M, 4 * c_, c2)
+        for i in (2, 1, 0):                                  # d m13 -> m9 -> m5 -> a1, accumulated into the lower slice
+            ops.maxpool5_bwd(dcat, b[tag + ".arg"][i], dcat, B, H, W, c_, lddy=4 * c_, lddx=4 * c_, dy_off=(i + 1) * c_, dx_off=i * c_,
+                             accumulate=True)
+        dz1 = self._conv_bwd(plan, tag + ".cv1", dcat, 4 * c_, 0)
+        din = plan.buf(tag + ".din", (M, c1))
+        ops.gemm_nt([SegSpec(dz1)], wT[pname + "cv1.conv.weight"], din, M, c1, c_)
         return din
 
     # ================================================================== backward
@@ -832,30 +959,50 @@ class Engine:
         h2, h4 = t // 2, t // 4
         # ---- Detect
         dzd = b["g.dzd"]
-        y10 = b["h7.cv3.y"]
-        ops.gemm_tn(dzd, [SegSpec(y10)], g["detect.8.m.0.weight"], T1, self.na * self.no, 128, ldy=48, lddw=128,
-                    dbias=g["detect.8.m.0.bias"])
-        dy10 = plan.buf("g.dy10", (T1, 128))
-        ops.gemm_nt([SegSpec(dzd)], wT["detect.8.m.0.weight"], dy10, T1, 128, 48)
-        # ---- C3 #2 on cat(up(y7), f0)
-        din7 = self._c3_bwd(plan, P, "h7", dy10, 128, 0)                     # [T1][384] = [d up(y7) 128 | d f0 256]
-        dy7 = plan.buf("g.dy7", (T2, 128))
-        ops.gather_sum_rows(din7, 384, dy7, 128, B, h2, h2, 1, 128)
-        dz4 = self._conv_bwd(plan, "h4", dy7, 128, 0)
-        dy6 = plan.buf("g.dy6", (T2, 256))
-        ops.gemm_nt([SegSpec(dz4)], wT["detect.4.conv.weight"], dy6, T2, 256, 128)
-        din3 = self._c3_bwd(plan, P, "h3", dy6, 256, 0)                      # [T2][512] = [d up(y3) 256 | d f1 256]
-        dy3 = plan.buf("g.dy3", (T3, 256))
-        ops.gather_sum_rows(din3, 512, dy3, 256, B, h4, h4, 1, 256)
-        dz0 = self._conv_bwd(plan, "h0", dy3, 256, 0)
-        df2 = plan.buf("g.df2", (T3, 512))
-        ops.gemm_nt([SegSpec(dz0)], wT["detect.0.conv.weight"], df2, T3, 512, 256)
+        hu = self._unit(self.head_out[0])
+        cd = self.head_out[1]
+        ops.gemm_tn(dzd, [SegSpec(b[self._unit_out_name(hu)])], g[self.det_name + "m.0.weight"], T1, self.na * self.no, cd, ldy=48, lddw=cd,
+                    dbias=g[self.det_name + "m.0.bias"])
+        dyd = plan.buf("g.dyd", (T1, cd))
+        ops.gemm_nt([SegSpec(dzd)], wT[self.det_name + "m.0.weight"], dyd, T1, cd, 48)
+        # ---- head units in reverse: every unit returns d(its concatenated input) [M][c1]; the gradient of an Upsample /
+        #      Concat input is a column slice of it (nearest x2^shr upsample: summed over the 2^shr x 2^shr children)
+        gout = {("unit", hu["k"]): (dyd, cd, 0)}                     # ref -> (buffer, ld, column offset)
+        for u in reversed(self.head_units):
+            H = t >> u["level"]
+            M = B * H * H
+            tag = f"h{u['k']}"
+            dy, ld, off = gout.pop(("unit", u["k"]))
+            if u["kind"] == "Conv":
+                dz = self._conv_bwd(plan, tag, dy, ld, off)
+                din = plan.buf(tag + ".din", (M, u["c1"]))
+                w_ = wT[f"detect.{u['k']}.conv.weight"]
+                if u["ksize"] == 1:
+                    ops.gemm_nt([SegSpec(dz)], w_, din, M, u["c1"], u["c2"])
+                else:
+                    segs = [SegSpec(dz, u["c2"], 0, -dy_, -dx_, 1, 0, H, H) for (dy_, dx_) in TAPS3]
+                    ops.gemm_nt(segs, w_, din, M, u["c1"], 9 * u["c2"], spatial=(H, H))
+            elif u["kind"] == "C3":
+                din = self._c3_bwd(plan, P, tag, dy, ld, off)
+            else:
+                din = self._spp_bwd(plan, P, tag, dy, ld, off)
+            coff = 0
+            for ref, c, shr in u["parts"]:
+                if shr == 0:
+                    gout[ref] = (din, u["c1"], coff)
+                else:
+                    Hs = H >> shr
+                    dsrc = plan.buf(f"{tag}.dup{coff}", (B * Hs * Hs, c))
+                    ops.gather_sum_rows(din, u["c1"], dsrc, c, B, Hs, Hs, shr, c, d_off=coff)
+                    gout[ref] = (dsrc, c, 0)
+                coff += c
+        (gf0, ld0, off0), (gf1, ld1, off1), (gf2, ld2, off2) = gout[("enc", 0)], gout[("enc", 1)], gout[("enc", 2)]
         # ---- neck3 + stage 3
         s3out = b["stage3.0.xo"]
-        ops.gemm_tn(df2, [SegSpec(s3out)], g[E + "neck3.weight"], T3, 512, 768)
+        ops.gemm_tn(gf2, [SegSpec(s3out)], g[E + "neck3.weight"], T3, 512, 768, ldy=ld2, y_off=off2)
         d3a = plan.buf("g.dA.768", (T3, 768))
         d3b = plan.buf("g.dB.768", (T3, 768))
-        ops.gemm_nt([SegSpec(df2)], wT[E + "neck3.weight"], d3a, T3, 768, 512)
+        ops.gemm_nt([SegSpec(gf2, 512, off2)], wT[E + "neck3.weight"], d3a, T3, 768, 512)
         self._block_bwd(plan, P, "stage3.0", enc.stage3[0], d3a, d3b)
         # head, neck 3 and stage 3 gradients are final: first data-parallel bucket (ddp.GradReducer.reduce_async)
         plan.bwd_marks.append((ops.recorded_count(), self.ddp_split3, self.flat_grad.numel()))
@@ -864,8 +1011,8 @@ class Engine:
         dB = plan.buf("g.dB.384", (T2, 384))
         self._merge_bwd(plan, P, "pmerging2", d3b, dA)
         s2out = b["stage2.3.xo"]
-        ops.gemm_tn(din3, [SegSpec(s2out)], g[E + "neck2.weight"], T2, 256, 384, ldy=512, y_off=256)
-        ops.gemm_nt([SegSpec(din3, 256, 256)], wT[E + "neck2.weight"], dA, T2, 384, 256, resid=dA)
+        ops.gemm_tn(gf1, [SegSpec(s2out)], g[E + "neck2.weight"], T2, 256, 384, ldy=ld1, y_off=off1)
+        ops.gemm_nt([SegSpec(gf1, 256, off1)], wT[E + "neck2.weight"], dA, T2, 384, 256, resid=dA)
         cur, other = dA, dB
         for i in reversed(range(4)):
             self._block_bwd(plan, P, f"stage2.{i}", enc.stage2[i], cur, other)
@@ -875,8 +1022,8 @@ class Engine:
         dB = plan.buf("g.dB.192", (T1, 192))
         self._merge_bwd(plan, P, "pmerging1", cur, dA)
         o4, o5 = b["stage1.4.xo"], b["stage1.5.xo"]
-        ops.gemm_tn(din7, [SegSpec(o4), SegSpec(o5)], g[E + "neck1.weight"], T1, 256, 384, ldy=384, y_off=128)
-        df0 = SegSpec(din7, 256, 128)
+        ops.gemm_tn(gf0, [SegSpec(o4), SegSpec(o5)], g[E + "neck1.weight"], T1, 256, 384, ldy=ld0, y_off=off0)
+        df0 = SegSpec(gf0, 256, off0)
         ops.gemm_nt([df0], wT[E + "neck1.weight"], dA, T1, 192, 256, w_off=192 * 256, resid=dA)        # d out5 += df0 @ Wn1[:,192:]
         # every gradient from PatchMerging 1 to the end of the flat buffer is final here: data-parallel runs start
         # their all-reduce now, under the stage-1 backward (ddp.GradReducer.reduce_async)

@@ -200,7 +200,7 @@ class C3(_Container):           # common.py:114-127
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
 
-class SPP(_Container):          # common.py:129-140; operator: spp.SPPOp (cascade of sodt_maxpool5 + K-segment concat)
+class SPP(_Container):          # common.py:129-140; engine._spp_fwd/_spp_bwd (cascade of sodt_maxpool5 + K-segment concat)
     def __init__(self, c1, c2, k=(5, 9, 13)):
         super().__init__()
         if tuple(k) != (5, 9, 13):

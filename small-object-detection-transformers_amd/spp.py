@@ -13,8 +13,10 @@ maxima (the tested case, tests/golden/spp.pt) the two agree; a map with exact ti
 quantisation after SiLU) gets the same total gradient mass per window placed on another tied element.
 
 model.yaml's head has no SPP (it appears in the SuperYOLO CNN configs this fork can no longer parse, SURVEY.md appendix
-C), so the engine's fixed graph does not call this; ``SPP`` in model.py holds the parameters with the reference's names
-and this module is the operator a graph with an SPP row would use.
+C).  A head yaml WITH an SPP row runs through ``Model(cfg)``: the engine's head walk (engine.Engine._check_head /
+_spp_fwd / _spp_bwd) places it as a graph node with plan-owned buffers (tests/test_head_graph_gpu.py, pinned against the
+reference's own parse_model + forward_once for that head).  This module is the same computation as a STANDALONE operator
+(own buffers, direct calls) - what tests/test_spp_gpu.py pins against the reference's ``common.SPP`` class.
 """
 from __future__ import annotations
 
