@@ -8,12 +8,12 @@
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     - the kernel BASELINE.json's north_star prices: the fused W-MSA / SW-MSA block kernel
-                 (csrc/wmsa_block.hip: LN1 + QKV + window attention + proj + residual + LN2 in one launch), the six
+                 (csrc/wmsa_hg.hip: LN1 + QKV + window attention + proj + residual + LN2 in one launch), the six
                  stage-1 launches of every step timed live with HIP events on the launch stream inside the timed
                  region; bound "mfma": achieved = 22.55 GFLOP x B per launch / average launch time, peak 2.5 PFLOP/s
                  dense bf16.  `traffic` = HBM bytes per launch from the PMC passes in profiles/ (FETCH_SIZE x 2 +
                  WRITE_SIZE, MI355X_MICROARCH.md), printed only when that profile was taken with the SAME kernel source
-                 (sha256 of csrc/wmsa_block.hip recorded in the file), else null
+                 (sha256 of csrc/wmsa_hg.hip recorded in the file), else null
   cpu_baseline - the CPU oracle (oracle/ref_torch.py, a port) timed on this host's cores, rank 0 at N=1 only:
                  B=1 @1024^2 directly and B=2 @512^2, fwd+bwd, 3 timed iterations each after a warm-up; `value` is the
                  median at 1024^2, both medians and bests are in `sample`
@@ -193,10 +193,11 @@ def main():
         kern_ms = sum(s_.elapsed_time(e_) for step_evs in evs for s_, e_ in step_evs) / (len(evs) * len(probe_idx))
         # algorithmic work of one launch: 8 T C^2 + 4 T N C flops with T = B t^2 tokens, C = 192, N = 64
         flops = 8.0 * Mrows * 192 * 192 + 4.0 * Mrows * 64 * 192
-        # algorithmic HBM bytes of one TRAINING launch: x in; x_mid, xn2, xn1, ao, q|k|v (3x) out = 9 token rows of C
-        # elements, + log-sum-exp (12 f32) and two (mean, rstd) pairs per token; inference: x in, x_mid + xn2 out
+        # algorithmic HBM bytes of one TRAINING launch: x in; x_mid, xn2, xn1, ao, q, k, v out = 8 token rows of C elements
+        # (rounds 1-2 counted 9: one row too many), + log-sum-exp (12 f32) and two (mean, rstd) pairs per token; inference:
+        # x in, x_mid + xn2 out
         es = 2 if a.dtype == "bf16" else 4
-        alg_bytes = Mrows * (9 * 192 * es + 12 * 4 + 16)
+        alg_bytes = Mrows * (8 * 192 * es + 12 * 4 + 16)
         achieved = flops / (kern_ms * 1e-3) / 1e12
         traffic, prof = None, None
         pdir = os.path.join(ROOT, "profiles")
@@ -204,7 +205,7 @@ def main():
         if tfiles and B == 8 and S == 1024 and a.dtype == "bf16":
             import hashlib
             tj = json.load(open(os.path.join(pdir, tfiles[-1])))
-            src = os.path.join(ROOT, PKG, "csrc", "wmsa_block.hip")
+            src = os.path.join(ROOT, PKG, "csrc", "wmsa_hg.hip")
             if tj.get("kernel_source_sha256") == hashlib.sha256(open(src, "rb").read()).hexdigest():
                 traffic, prof = tj["hbm_bytes_per_launch"], tfiles[-1]
         img_s = world * B * a.steps / dt
@@ -218,8 +219,8 @@ def main():
             "model_tflops": round(img_s * FLOP_PER_IMG_1024 * (S / 1024) ** 2 / 1e12, 1),
             # the kernel north_star prices at the MFMA roofline (fused AI 448 flop/B in inference form; the training launch also
             # writes the tensors saved for backward, 4.5x the bytes, which is what bounds it: see hbm_*)
-            "roofline": {"bound": "mfma", "kernel": "wmsa_block_kernel<%s, save-for-backward> stage 1 (C=192, 12x16, 8x8 windows, shift 0|2): "
-                                                    "LN1+QKV+W-MSA+proj+residual+LN2, %d launches/step" % (a.dtype, len(probe_idx)),
+            "roofline": {"bound": "mfma", "kernel": "%s<save-for-backward> stage 1 (C=192, 12x16, 8x8 windows, shift 0|2): "
+                                                    "LN1+QKV+W-MSA+proj+residual+LN2, %d launches/step" % ("wmsa_hg_kernel (bf16, four waves per window)" if a.dtype == "bf16" else "wmsa_block_kernel<f32>", len(probe_idx)),
                          "achieved": round(achieved, 1), "peak": PEAK_BF16 if a.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                          "frac": round(achieved / (PEAK_BF16 if a.dtype == "bf16" else 157.3), 4),
                          "avg_launch_ms": round(kern_ms, 4), "flops_per_launch": flops, "algorithmic_bytes": alg_bytes,

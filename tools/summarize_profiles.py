@@ -10,7 +10,7 @@ shutil.copy(st, f"profiles/{tag}_kernel_stats.csv")
 rows = list(csv.DictReader(open(st)))
 bench = json.loads([l for l in open(f"{src}/stats.log") if l.startswith('{"metric"')][0])
 steps = bench["steps"] + max(bench["warmup"], 2)
-KEY = "wmsa_block_kernelIDF16bLi4ELi2ELb1E"      # bf16, 4 waves, double-buffered stages, save-for-backward
+KEY = "wmsa_hg_kernel<true, false>"      # four-waves-per-window bf16 kernel (csrc/wmsa_hg.hip), save-for-backward, no stamps
 
 
 def dispatches(path, key, name=None):
@@ -28,9 +28,9 @@ kt = dispatches(glob.glob(f"{src}/stats/*/*kernel_trace.csv")[0], KEY)
 fetch_kb, write_kb = sum(v for _, v in fe) / len(fe), sum(v for _, v in wr) / len(wr)
 avg_ns = sum(d for d, _ in kt) / len(kt)
 flops = bench["roofline"]["flops_per_launch"]
-ksrc = "small-object-detection-transformers_amd/csrc/wmsa_block.hip"
+ksrc = "small-object-detection-transformers_amd/csrc/wmsa_hg.hip"
 traffic = {
-    "kernel": "wmsa_block_kernel<bf16, 4 waves, 2 stages, save-for-backward> (stage-1 launches of bench.py)", "launches_sampled": len(fe),
+    "kernel": "wmsa_hg_kernel<save-for-backward> (bf16, 8 waves = 2 windows per workgroup; stage-1 launches of bench.py)", "launches_sampled": len(fe),
     "kernel_source_sha256": hashlib.sha256(open(ksrc, "rb").read()).hexdigest(),
     "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
     "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane streaming reads -> x2; "
@@ -46,7 +46,7 @@ with open(f"profiles/{tag}_summary.md", "w") as f:
     f.write(f"{bench['value']} img/s, {bench['ms_per_step']} ms/step; totals over the {steps} traced steps.\n\n| kernel | calls | ms/step | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows[:24]:
         f.write(f"| `{r['Name'][:100]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6/steps:.2f} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |\n")
-    f.write(f"\nRoofline kernel (`wmsa_block_kernel<bf16, save>`): kernel-trace average {avg_ns/1e3:.1f} us over {len(kt)} launches = "
+    f.write(f"\nRoofline kernel (`wmsa_hg_kernel<save>`): kernel-trace average {avg_ns/1e3:.1f} us over {len(kt)} launches = "
             f"{flops/(avg_ns*1e-9)/1e12:.1f} TFLOP/s = {traffic['mfma_frac_from_trace']:.4f} of 2.5 PFLOP/s (bench.py's live HIP-event figure: "
             f"{bench['roofline']['avg_launch_ms']*1e3:.1f} us, frac {bench['roofline']['frac']}); HBM traffic per launch "
             f"{traffic['hbm_bytes_per_launch']/1e6:.0f} MB (FETCH_SIZE {fetch_kb:.0f} KB x2 + WRITE_SIZE {write_kb:.0f} KB) vs "
