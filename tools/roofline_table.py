@@ -53,7 +53,7 @@ def cost(name, args):
     if name == "sodt_wmsa_block_fwd":
         B, H, W, C = (val(args[i]) for i in (10, 11, 12, 13))
         T = B * H * W
-        return (f"T={T} C={C} train", T * (9 * C * ES + 12 * 4 + 16), 8.0 * T * C * C + 4.0 * T * 64 * C)
+        return (f"T={T} C={C} train", T * (8 * C * ES + 12 * 4 + 16), 8.0 * T * C * C + 4.0 * T * 64 * C)
     if name in ("sodt_window_attn_fwd", "sodt_window_attn_bwd", "sodt_window_attn_bwd_wm"):
         o = {"sodt_window_attn_fwd": 4, "sodt_window_attn_bwd": 8, "sodt_window_attn_bwd_wm": 6}[name]
         B, H, W, C, heads, ws = (val(args[o + i]) for i in range(6))
