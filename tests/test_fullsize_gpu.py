@@ -60,6 +60,39 @@ def test_fullsize_f32_gradients_vs_oracle(dev):
     assert worst[1] <= 2e-3, f"1024^2 f32 gradient vs oracle autograd: {worst}"
 
 
+def test_config1_b2_512_train_step_vs_oracle(dev):
+    """BASELINE.json configs[0] as stated: 2 x 512 x 512 RGB+IR through the CPU reference path - here the oracle (pinned to the
+    reference at this resolution) - against the f32 engine: logits, encoder features and element-wise gradients of a spread of
+    parameters for a B = 2 training step (BatchNorm statistics couple the two images)."""
+    from oracle import ref_torch as R
+    torch.set_num_threads(16)
+    model, sd = build(dev, 512)
+    model.compute_dtype = torch.float32
+    model.train()
+    x_rgb, x_ir = R.synthetic_inputs(2, 512, seed=12)
+    pred, y = model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
+    pred[0].square().mean().backward()
+    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "anchor" not in k) for k, v in sd.items()}
+    opred, oy = R.model_forward(osd, x_rgb, x_ir, True, {})
+    opred[0].square().mean().backward()
+    e, s = rel(pred[0].detach(), opred[0].detach())
+    assert e <= 1e-3, f"B=2 @512^2 f32 logits vs oracle: {e:.3e} (|logit| max {s:.2f})"
+    for i in range(3):
+        e, s = rel(y[i], oy[i].detach())
+        assert e <= 1e-3 * max(1.0, s), (i, e)
+    params = dict(model.named_parameters())
+    E = "image_encoder."
+    worst = ("", 0.0)
+    for n in (E + "patch_embed.proj.weight", E + "stage1.2.attn.relative_position_bias_table", E + "stage1.5.mlp.conv1.weight",
+              E + "stage2.2.attn.qkv.weight", E + "pmerging2.reduction.weight", E + "stage3.0.mlp.fc1.weight", E + "neck2.weight",
+              "detect.0.bn.weight", "detect.3.cv3.conv.weight", "detect.7.m.0.cv2.conv.weight", "detect.8.m.0.bias"):
+        ref = osd[n].grad.double()
+        r = float((params[n].grad.double().cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        if r > worst[1]:
+            worst = (n, r)
+    assert worst[1] <= 2e-3, f"B=2 @512^2 gradient vs oracle autograd: {worst}"
+
+
 def test_batch_of_8_is_8_independent_images_bf16(dev):
     from oracle import ref_torch as R
     model, _ = build(dev, 1024)
