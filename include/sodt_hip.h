@@ -163,8 +163,6 @@ int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, void* xn2, flo
 int sodt_debug_wmsa_stamps(long long* out_host_256x8, int enable);
 /* the same for the four-waves-per-window bf16 kernel (csrc/wmsa_hg.hip): 12 phases per workgroup */
 int sodt_debug_wmsa_hg_stamps(long long* out_host_512x12, int enable);
-/* the same for the de-phased variant (csrc/wmsa_hg2.hip): 24 slot-work + 24 hand-over sums per wave */
-int sodt_debug_wmsa_hg2_stamps(long long* out_host_512x48, int enable);
 /* sodt_window_attn_bwd on the window-major qkvw / lsew of sodt_wmsa_block_fwd (8x8 windows, head_dim 16);
  * dout and dqkv keep the natural layouts [M][C] / [M][3C]. */
 int sodt_window_attn_bwd_wm(const void* qkvw, const float* bias_t, const void* dout, const float* lsew,

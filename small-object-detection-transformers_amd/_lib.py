@@ -106,7 +106,6 @@ SIGNATURES = {
     "sodt_preprocess_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "sodt_debug_wmsa_stamps": [_P, _I],
     "sodt_debug_wmsa_hg_stamps": [_P, _I],
-    "sodt_debug_wmsa_hg2_stamps": [_P, _I],
 }
 
 _lib = None

@@ -697,8 +697,7 @@ extern "C" int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, voi
   if (dtype == SODT_BF16) {
     // throughput path: four waves per window (wmsa_hg.hip); SODT_WMSA_ONE_WAVE=1 keeps the one-wave-per-window kernel below
     static const bool one_wave = getenv("SODT_WMSA_ONE_WAVE") != nullptr && getenv("SODT_WMSA_ONE_WAVE")[0] == '1';
-    static const bool hg2 = getenv("SODT_WMSA_HG2") != nullptr && getenv("SODT_WMSA_HG2")[0] == '1';
-    if (!one_wave && !g_wmsa_stamp_enable) return hg2 ? wmsa_hg2_launch(a, save, st) : wmsa_hg_launch(a, save, st);
+    if (!one_wave && !g_wmsa_stamp_enable) return wmsa_hg_launch(a, save, st);
     if (g_wmsa_stamp_enable) return save ? launch_block<bf16, 4, 2, true, true>(a, st) : launch_block<bf16, 4, 2, false, true>(a, st);
     return save ? launch_block<bf16, 4, 2, true>(a, st) : launch_block<bf16, 4, 2, false>(a, st);
   }

@@ -14,7 +14,6 @@ struct WArgs {
   int dbg;      // diagnostic ablations of wmsa_hg.hip (SODT_HG_DBG; results are wrong when non-zero): 1 = no weight DMA after the first, 2 = no output stores
 };
 int wmsa_hg_launch(const WArgs& a, bool save, hipStream_t st);     // wmsa_hg.hip
-int wmsa_hg2_launch(const WArgs& a, bool save, hipStream_t st);    // wmsa_hg2.hip (the two windows of a workgroup de-phased)
 
 namespace {
 

@@ -86,20 +86,3 @@ if "--hg-stamps" in sys.argv:
         for i, n in enumerate(names):
             print(f"   {n:20s} {t2[0][:, i].mean() / npair:8.0f} ({100 * t2[0][:, i].mean() / tot:5.1f} %) | {t2[1][:, i].mean() / npair:8.0f}")
 
-if "--hg2-stamps" in sys.argv:       # run with SODT_WMSA_HG2=1
-    import ctypes
-    lib = L.load()
-    names = ["L"] + [f"{n}{i}" for i in range(3) for n in ("QX", "QY", "Sa", "Sb", "Sc", "Sd")] + ["T", "PX", "PY", "G", "E"]
-    for label, fn in (("inference", lambda: ops.wmsa_block_fwd(x, wpk, xm, xn2, None, None, None, None, None, None, B, H, H, C, HEADS, WS, 0)),
-                      ("training", lambda: ops.wmsa_block_fwd(x, wpk, xm, xn2, st1, st2, xn1, qkvw, lsew, ao, B, H, H, C, HEADS, WS, 0))):
-        lib.sodt_debug_wmsa_hg2_stamps(None, 1)
-        fn(); torch.cuda.synchronize(); big.zero_(); fn(); torch.cuda.synchronize()
-        buf = (ctypes.c_longlong * (512 * 48))()
-        lib.sodt_debug_wmsa_hg2_stamps(buf, 0)
-        t2 = torch.tensor(list(buf), dtype=torch.float64).view(2, 256, 48)
-        npair = M / 64 / 2 / 256
-        tot = t2[0].sum(1).mean()
-        print(f"hg2 stamps ({label}; cycles per launch {tot:.0f}, {tot / npair:.0f} per window pair); per pair, work + hand-over: window A (wave 0) | window B (wave 4)")
-        for i, n in enumerate(names):
-            a0, a1, b0, b1 = (t2[k][:, i + o].mean() / npair for k in (0, 1) for o in (0, 24))
-            print(f"   {n:4s} {a0:6.0f} + {a1:6.0f} | {b0:6.0f} + {b1:6.0f}")
