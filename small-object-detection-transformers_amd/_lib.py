@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsodt_hip.so")
+LIB_PATH = os.environ.get("SODT_LIB_PATH") or os.path.join(HERE, "libsodt_hip.so")     # (override: A/B of experimental builds, tools/exp)
 
 MAX_SEG = 9
 F32, BF16 = 0, 1

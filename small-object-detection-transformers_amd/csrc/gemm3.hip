@@ -19,6 +19,19 @@
 // 160 KB reads + 56 KB DMA writes per CU against 1536 MFMA cycles per SIMD.
 #include "gemm_epi.h"
 
+// scheduling experiments (tools/exp/ab_gemm3.sh): SODT_EXP_PRIO 1 = s_setprio(1) around every MFMA cluster (keeps hipcc from
+// moving MFMAs across the raw barriers: cdna_hip_programming.md T5); 2 = static priority for the younger half of the workgroup
+#ifndef SODT_EXP_PRIO
+#define SODT_EXP_PRIO 0
+#endif
+#if SODT_EXP_PRIO == 1
+#define T3_PRIO_HI() __builtin_amdgcn_s_setprio(1)
+#define T3_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define T3_PRIO_HI() do {} while (0)
+#define T3_PRIO_LO() do {} while (0)
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -92,6 +105,9 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   const int wr = wid >> 1, wc = wid & 1;
   const int fi = lane & 15, fg = lane >> 4;
   const uint32_t lbase = lds_addr(dsm);
+#if SODT_EXP_PRIO == 2
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
 
   if (tid == 0) {                  // own padded copy of the segment table (16-byte aligned fields)
 #pragma unroll
@@ -261,6 +277,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
       u32x4 fw2 = lds_rd128<4096>(WRD + bo), fw3 = lds_rd128<4608>(WRD + bo);         \
       u32x4 fw4 = lds_rd128<8192>(WRD + bo), fw5 = lds_rd128<8704>(WRD + bo);         \
       T3_LGKM0();                                                                    \
+      T3_PRIO_HI();                                                                  \
       mma_sw(acc[0][0][0], fw0, fa0); mma_sw(acc[0][0][1], fw1, fa0);                \
       mma_sw(acc[0][1][0], fw2, fa0); mma_sw(acc[0][1][1], fw3, fa0);                \
       mma_sw(acc[0][2][0], fw4, fa0); mma_sw(acc[0][2][1], fw5, fa0);                \
@@ -273,6 +290,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
       mma_sw(acc[3][0][0], fw0, fa3); mma_sw(acc[3][0][1], fw1, fa3);                \
       mma_sw(acc[3][1][0], fw2, fa3); mma_sw(acc[3][1][1], fw3, fa3);                \
       mma_sw(acc[3][2][0], fw4, fa3); mma_sw(acc[3][2][1], fw5, fa3);                \
+      T3_PRIO_LO();                                                                  \
     }
     T3_KB(aRd0, wRd0)
     if (PRE || RC) __builtin_amdgcn_sched_barrier(0);   // keep the second half's fragment reads behind the first half's MFMAs:
@@ -404,6 +422,9 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const sodt_gemm_tn_args g
   const int wr = wid >> 1, wc = wid & 1;
   const int fr = lane & 15, fg = lane >> 4;
   const uint32_t lbase = lds_addr(dsm);
+#if SODT_EXP_PRIO == 2
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
   if (tid == 0) {
 #pragma unroll
     for (int j = 0; j < SODT_MAX_SEG; ++j) {
@@ -563,10 +584,12 @@ __global__ __launch_bounds__(512) void gemm_tn3_kernel(const sodt_gemm_tn_args g
 #pragma unroll
       for (int j = 0; j < 6; ++j) fq[j] = tn3_frag<1536>(qa[j] + so);
       T3_LGKM0();
+      T3_PRIO_HI();
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) mma_sw(acc[i][j], fp[i], fq[j]);
+      T3_PRIO_LO();
       if (do_bias) {
         if (SWAP) {
 #pragma unroll
