@@ -215,7 +215,11 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
     // W(0) was requested before the previous pair's epilogue stores (or at kernel start): everything older than the
     // youngest stores has landed.  The stores themselves stay in flight.
     HG_STAMP(0);
-    if (SAVE) HG_VMWAIT(0); else HG_VMWAIT(12);
+    // (inference: the 12 x_mid / xn2 stores of the previous pair; training: + its LN2 statistics and this pair's LN1 statistics
+    //  and xn1 rows, 20 in all - a wave of a clamped tail window issued fewer and waits for everything)
+    if (!SAVE) HG_VMWAIT(12);
+    else if (valid) HG_VMWAIT(20);
+    else HG_VMWAIT(0);
     __syncthreads();                                     // B1: tiles complete, W(0) visible
     HG_STAMP(1);
 
