@@ -4,7 +4,7 @@
 set -e
 F=$1; FLAGS=$2; TAG=$3
 P=small-object-detection-transformers_amd
-hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wno-unused-value $FLAGS -c $P/csrc/$F.hip -o $P/build/${F}_$TAG.o
-OBJS=$(ls $P/build/*.o | grep -v "_v[0-9a-z]*\.o" | grep -v "/$F.o")
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wno-unused-value -Wno-inline-asm $FLAGS -c $P/csrc/$F.hip -o $P/build/${F}_$TAG.o
+OBJS=$(for f in $P/csrc/*.hip; do n=$(basename $f .hip); if [ "$n" != "$F" ]; then echo $P/build/$n.o; fi; done)
 hipcc -shared -fPIC --offload-arch=gfx950 $OBJS $P/build/${F}_$TAG.o -o $P/libsodt_hip_$TAG.so
 echo built $P/libsodt_hip_$TAG.so
