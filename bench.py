@@ -96,6 +96,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    # A timed number must come from the in-tree library running every store and every copy: refuse the diagnostic switches
+    # (SODT_LIB_PATH swaps the whole .so for an A/B build; the retired SODT_HG_DBG / SODT_WMSA_ONE_WAVE used to ablate the
+    # fused kernel).  Checked before anything touches the GPU or spawns ranks; tests/test_abi_and_host.py asserts it.
+    diag = [k for k in ("SODT_LIB_PATH", "SODT_HG_DBG", "SODT_WMSA_ONE_WAVE") if os.environ.get(k)]
+    if diag:
+        print(f"bench.py: refusing to run with diagnostic environment switch(es) set: {', '.join(diag)}", file=sys.stderr)
+        raise SystemExit(2)
+
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as typed: this parent never touches the GPU; it starts one rank per GPU through
         # torch.distributed.run (the same launch the driver uses), forwards their output and exits with their status

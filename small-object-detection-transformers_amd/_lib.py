@@ -9,7 +9,18 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SODT_LIB_PATH") or os.path.join(HERE, "libsodt_hip.so")     # (override: A/B of experimental builds, tools/exp)
+DEFAULT_LIB_PATH = os.path.join(HERE, "libsodt_hip.so")
+# SODT_LIB_PATH swaps in an experimental build (tools/exp/ab_build.sh) for A/B timing on one box.  It is a tools-only switch:
+# overrides() reports it, ops.version() carries it, and bench.py refuses to run with it set.
+LIB_PATH = os.environ.get("SODT_LIB_PATH") or DEFAULT_LIB_PATH
+# environment switches that change WHICH native code runs or what it skips; the library itself reads none of them any more
+# (round 4), the names stay listed so that bench.py also refuses the retired ones instead of silently ignoring a typo'd intent
+DIAGNOSTIC_ENV = ("SODT_LIB_PATH", "SODT_HG_DBG", "SODT_WMSA_ONE_WAVE")
+
+
+def overrides():
+    """Diagnostic environment switches that are set in this process (empty for a product run)."""
+    return {k: os.environ[k] for k in DIAGNOSTIC_ENV if os.environ.get(k)}
 
 MAX_SEG = 9
 F32, BF16 = 0, 1

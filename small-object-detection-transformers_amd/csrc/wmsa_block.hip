@@ -691,15 +691,13 @@ extern "C" int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, voi
   a.x = (const unsigned char*)x; a.wpk = (const unsigned char*)wpk;
   a.xm = (unsigned char*)xm; a.xn2 = (unsigned char*)xn2; a.st1 = st1; a.st2 = st2;
   a.xn1 = (unsigned char*)xn1; a.qkvw = (unsigned char*)qkvw; a.lsew = lsew; a.ao = (unsigned char*)ao;
-  a.dbg = 0;
   a.B = B; a.H = H; a.W = W; a.shift = shift; a.nwy = H / WWS; a.nwx = W / WWS; a.nwin = B * a.nwy * a.nwx;
   hipStream_t st = (hipStream_t)st_;
   if (dtype == SODT_BF16) {
-    // throughput path: four waves per window (wmsa_hg.hip); SODT_WMSA_ONE_WAVE=1 keeps the one-wave-per-window kernel below
-    static const bool one_wave = getenv("SODT_WMSA_ONE_WAVE") != nullptr && getenv("SODT_WMSA_ONE_WAVE")[0] == '1';
-    if (!one_wave && !g_wmsa_stamp_enable) return wmsa_hg_launch(a, save, st);
-    if (g_wmsa_stamp_enable) return save ? launch_block<bf16, 4, 2, true, true>(a, st) : launch_block<bf16, 4, 2, false, true>(a, st);
-    return save ? launch_block<bf16, 4, 2, true>(a, st) : launch_block<bf16, 4, 2, false>(a, st);
+    // throughput path: four waves per window (wmsa_hg.hip).  The one-wave-per-window bf16 build below only runs as the
+    // instrumented diagnostic build armed through sodt_debug_wmsa_stamps (an explicit API call, no environment switch).
+    if (!g_wmsa_stamp_enable) return wmsa_hg_launch(a, save, st);
+    return save ? launch_block<bf16, 4, 2, true, true>(a, st) : launch_block<bf16, 4, 2, false, true>(a, st);
   }
   if (dtype == SODT_F32) return save ? launch_block<float, 2, 1, true>(a, st) : launch_block<float, 2, 1, false>(a, st);
   return SODT_EINVAL;

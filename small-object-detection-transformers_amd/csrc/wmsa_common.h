@@ -11,7 +11,6 @@ struct WArgs {
   unsigned char* xm; unsigned char* xn2; float* st1; float* st2;
   unsigned char* xn1; unsigned char* qkvw; float* lsew; unsigned char* ao;
   int B, H, W, shift, nwy, nwx, nwin;
-  int dbg;      // diagnostic ablations of wmsa_hg.hip (SODT_HG_DBG; results are wrong when non-zero): 1 = no weight DMA after the first, 2 = no output stores
 };
 int wmsa_hg_launch(const WArgs& a, bool save, hipStream_t st);     // wmsa_hg.hip
 

@@ -25,7 +25,6 @@
 //
 // LDS: 2 x 24 KB tiles + 72 KB weights + 25.5 KB tables + 3.75 KB vectors (+ 8 KB v patches when saving) = 157.25 KB.
 #include "wmsa_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -89,7 +88,9 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
   // pieces q0 .. q1 - 1 of this wave's nine: the issue of a 1 KB piece stalls the wave for 100+ cycles while the CU's address
   // path works through the burst, so the nine are spread over the VALU work of the phase that hides the copy
   auto dma_part = [&](int stage, int q0, int q1) {
-    if (a.dbg & 1) return;
+#ifdef SODT_HG_ABLATE_DMA      // timing-only A/B build (tools/exp/ab_build.sh): never defined in the library build
+    return;
+#endif
     const unsigned char* gsrc = a.wpk + L::HGW_OFF + (size_t)stage * HG_WBUF;     // the stages are one contiguous stream
 #pragma unroll
     for (int q = q0; q < q1; ++q) {
@@ -493,7 +494,11 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
         for (int k = 0; k < KPL; ++k) { const float d = v[i][k] - mu; q = fmaf(d, d, q); }
       q = rows_sum(q);
       const float rs = rsqrtf(q * (1.0f / WC) + 1e-5f);
-      if (valid && !(a.dbg & 2)) {
+#ifdef SODT_HG_ABLATE_STORES   // timing-only A/B build (tools/exp/ab_build.sh): never defined in the library build
+      if (false) {
+#else
+      if (valid) {
+#endif
         if (SAVE && gl == 0) *(float2*)((unsigned char*)a.st2 + myrow * 8u) = make_float2(mu, rs);
 #pragma unroll
         for (int i = 0; i < 6; ++i) *(uint4*)(a.xm + (myoff + 64u * i)) = pack<T>(v[i]);
@@ -546,10 +551,7 @@ int hg_launch(const WArgs& a, hipStream_t st) {
 
 }  // namespace
 
-int wmsa_hg_launch(const WArgs& a_, bool save, hipStream_t st) {
-  WArgs a = a_;
-  static const int dbg = getenv("SODT_HG_DBG") ? atoi(getenv("SODT_HG_DBG")) : 0;
-  a.dbg = dbg;
+int wmsa_hg_launch(const WArgs& a, bool save, hipStream_t st) {
   if (g_hg_stamp_enable) return save ? hg_launch<true, true>(a, st) : hg_launch<false, true>(a, st);
   return save ? hg_launch<true>(a, st) : hg_launch<false>(a, st);
 }

@@ -155,6 +155,7 @@ class Engine:
         self.img_t = enc.pos_embed.shape[1]
         det = model.detect[-1]
         self.na, self.no, self.nc = det.na, det.no, det.nc
+        self.det_np = (det.na * det.no + 15) // 16 * 16      # Detect GEMM width, zero-padded to a multiple of 16 (39 -> 48 at nc = 8)
         self.fused = not any(type(m).__name__ == "BatchNorm2d" for m in model.detect.modules())
         self._check_head()
         self.plans: Dict[Tuple, Plan] = {}
@@ -912,8 +913,8 @@ class Engine:
         if self.ddp is not None:
             self.ddp.begin_backward(self.flat_grad, fresh)
         # (1) Detect backward: live (dpred pointer changes)
-        dzd = plan.buf("g.dzd", (T1, 48))
-        ops.detect_unpermute(dpred, dzd, 48, B, t * t, self.na, self.no)
+        dzd = plan.buf("g.dzd", (T1, self.det_np))
+        ops.detect_unpermute(dpred, dzd, self.det_np, B, t * t, self.na, self.no)
         overlap = False
         if plan.bwd_main is None:
             with ops.Recorder() as rec:
@@ -961,10 +962,10 @@ class Engine:
         dzd = b["g.dzd"]
         hu = self._unit(self.head_out[0])
         cd = self.head_out[1]
-        ops.gemm_tn(dzd, [SegSpec(b[self._unit_out_name(hu)])], g[self.det_name + "m.0.weight"], T1, self.na * self.no, cd, ldy=48, lddw=cd,
+        ops.gemm_tn(dzd, [SegSpec(b[self._unit_out_name(hu)])], g[self.det_name + "m.0.weight"], T1, self.na * self.no, cd, ldy=self.det_np, lddw=cd,
                     dbias=g[self.det_name + "m.0.bias"])
         dyd = plan.buf("g.dyd", (T1, cd))
-        ops.gemm_nt([SegSpec(dzd)], wT[self.det_name + "m.0.weight"], dyd, T1, cd, 48)
+        ops.gemm_nt([SegSpec(dzd)], wT[self.det_name + "m.0.weight"], dyd, T1, cd, self.det_np)
         # ---- head units in reverse: every unit returns d(its concatenated input) [M][c1]; the gradient of an Upsample /
         #      Concat input is a column slice of it (nearest x2^shr upsample: summed over the 2^shr x 2^shr children)
         gout = {("unit", hu["k"]): (dyd, cd, 0)}                     # ref -> (buffer, ld, column offset)

@@ -418,4 +418,7 @@ def gemm_set_variant(v) -> None:
 
 
 def version() -> str:
-    return _lib.sodt_version().decode()
+    """Version string of the loaded library; a non-default library path (SODT_LIB_PATH) is part of it."""
+    v = _lib.sodt_version().decode()
+    ov = L.overrides() if hasattr(L, "overrides") else {}
+    return v + (" [" + ", ".join(f"{k}={x}" for k, x in sorted(ov.items())) + "]" if ov else "")

@@ -46,6 +46,33 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
         L.load()
 
 
+@pytest.mark.parametrize("var", ["SODT_LIB_PATH", "SODT_HG_DBG", "SODT_WMSA_ONE_WAVE"])
+def test_bench_refuses_diagnostic_environment(var):
+    """a timed number must not come from an ablated kernel or a swapped library."""
+    import subprocess
+    import sys
+    env = dict(os.environ, **{var: "1"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert var in r.stderr and "refusing" in r.stderr
+    assert r.stdout.strip() == ""          # no JSON line
+
+
+def test_library_reads_no_environment_switch():
+    """The ablation paths of the fused kernel are compile-time macros of the tools/exp A/B build, not run-time switches."""
+    csrc = os.path.join(ROOT, "small-object-detection-transformers_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_version_reports_library_override(pkg, ops, monkeypatch):
+    assert pkg._lib.overrides() == {} or "SODT_LIB_PATH" in os.environ
+    monkeypatch.setenv("SODT_HG_DBG", "3")
+    assert pkg._lib.overrides().get("SODT_HG_DBG") == "3"
+    assert "SODT_HG_DBG=3" in ops.version()
+
+
 @pytest.fixture(scope="module")
 def M(pkg):
     return importlib.import_module("small-object-detection-transformers_amd.model")
