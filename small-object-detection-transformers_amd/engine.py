@@ -931,7 +931,28 @@ class Engine:
             ops.replay(plan.bwd_main, probes=self.probes_bwd, start=pos)
         else:
             self._replay(plan, "bwd_main", plan.bwd_main, self.probes_bwd)
+        self._frontend_bwd(plan, P, x_rgb, x_ir)
+        if self.ddp is not None:
+            if overlap:
+                self.ddp.finish(self.flat_grad[:self.ddp_split])
+            else:
+                self.ddp.reduce(self.flat_grad)
+
+    def replay_encoder_backward(self, plan: Plan, x_rgb, x_ir):
+        """Diagnostic / test hook: re-run the ENCODER part of the recorded backward (necks, stages 3..1, PatchMergings, patch
+        embed, front end) from whatever the head-input gradient buffers `plan.enc_gin` hold now, accumulating into the flat
+        gradient buffer.  The encoder has no cross-image coupling (LayerNorm, windows, per-image shifts), so a batch's encoder
+        gradients are the sum of its images' - tests/test_fullsize_gpu.py checks the B = 8 training step that way.  Needs one
+        ordinary backward on this plan first (it records the launches) and the activations of the latest forward."""
+        if plan.bwd_main is None or getattr(plan, "enc_bwd_start", None) is None:
+            raise RuntimeError("replay_encoder_backward: run one backward on this plan first")
+        ops.replay(plan.bwd_main, start=plan.enc_bwd_start)
+        self._frontend_bwd(plan, self._prep_for(plan.dt), x_rgb, x_ir)
+
+    def _frontend_bwd(self, plan: Plan, P, x_rgb, x_ir):
         # (3) front end: live
+        B, S = plan.B, plan.S
+        t = S // 4
         fe = P["fe"]
         cb = self.model.image_encoder.chan_block
         ca_ws, ca_shift = int(cb.window_size), int(cb.shift_size)
@@ -944,11 +965,6 @@ class Engine:
             ops.zero_(de)
             ops.cross_attn_ln_bwd(plan.bufs["fe.e"], fe["g"], plan.bufs["g.dx0"], de, self.g_fe_g, self.g_fe_be, B, S, ca_ws, ca_shift)
             ops.patch_embed4_bwd(x_rgb, x_ir, x_ir.shape[1] * S * S, de, self.g_fe_w, self.g_fe_b, B, S)
-        if self.ddp is not None:
-            if overlap:
-                self.ddp.finish(self.flat_grad[:self.ddp_split])
-            else:
-                self.ddp.reduce(self.flat_grad)
 
     def _backward_main(self, plan: Plan, P):
         B, S = plan.B, plan.S
@@ -998,6 +1014,10 @@ class Engine:
                     gout[ref] = (dsrc, c, 0)
                 coff += c
         (gf0, ld0, off0), (gf1, ld1, off1), (gf2, ld2, off2) = gout[("enc", 0)], gout[("enc", 1)], gout[("enc", 2)]
+        # where the head's backward ends and the encoder's begins, and the buffers the head left d(f0), d(f1), d(f2) in
+        # (token-major rows, `ld` columns, the feature's columns at `off`): replay_encoder_backward re-runs the rest from there
+        plan.enc_bwd_start = ops.recorded_count()
+        plan.enc_gin = [(gf0, ld0, off0, 256), (gf1, ld1, off1, 256), (gf2, ld2, off2, 512)]
         # ---- neck3 + stage 3
         s3out = b["stage3.0.xo"]
         ops.gemm_tn(gf2, [SegSpec(s3out)], g[E + "neck3.weight"], T3, 512, 768, ldy=ld2, y_off=off2)
