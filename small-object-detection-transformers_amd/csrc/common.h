@@ -176,6 +176,12 @@ __device__ __forceinline__ float group16_sum(float v) {
   v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
   return v;
 }
+// sum over the 8 consecutive lanes l & ~7 .. l | 7 (quad xor 1, xor 2, then the mirror inside each half row); every lane ends
+// with the result
+__device__ __forceinline__ float group8_sum(float v) {
+  v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v);
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
   v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);

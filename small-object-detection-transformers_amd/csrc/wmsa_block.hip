@@ -613,9 +613,11 @@ __global__ __launch_bounds__(256) void wmsa_pack_kernel(const float* __restrict_
     T* dst = (T*)(sb + sect * L::WFRAG);
     for (int e = tid; e < L::KSTEPS * 64 * KPL; e += 256) {
       const int kk = e / (64 * KPL), l = (e / KPL) % 64, j = e % KPL;
-      dst[e] = from_f<T>(qkv_w[(long)(sect * WC + WHD * h + (l & 15)) * WC + KU * kk + KPL * (l >> 4) + j]);
-      if constexpr (L::HGW_BYTES > 0)      // the same fragments in the contiguous stream of wmsa_hg.hip
-        ((T*)(wpk + L::HGW_OFF + (long)h * 3 * L::WFRAG + sect * L::WFRAG))[e] = dst[e];
+      const float wv_ = qkv_w[(long)(sect * WC + WHD * h + (l & 15)) * WC + KU * kk + KPL * (l >> 4) + j];
+      dst[e] = from_f<T>(wv_);
+      if constexpr (L::HGW_BYTES > 0)      // the same fragments in the contiguous stream of wmsa_hg.hip; there Wq (and the q bias
+        //                                    copy below) carry hd^-1/2 x log2 e, so S^T leaves the MFMA ready for exp2
+        ((T*)(wpk + L::HGW_OFF + (long)h * 3 * L::WFRAG + sect * L::WFRAG))[e] = from_f<T>(sect == 0 ? wv_ * (0.25f * WMSA_LOG2E) : wv_);
     }
   }
   // relative-position bias of this head x log2 e: copy v, row dyi, position i holds table[dyi][14 - (i + v)]
@@ -627,7 +629,9 @@ __global__ __launch_bounds__(256) void wmsa_pack_kernel(const float* __restrict_
     }
   }
   float* bq = (float*)(sb + L::BQKV_OFF);
-  for (int i = tid; i < 64; i += 256) bq[i] = i < 48 ? qkv_b[(i / 16) * WC + WHD * h + (i % 16)] : 0.f;
+  // [48..63]: the q bias x hd^-1/2 x log2 e (wmsa_hg.hip's scaled q)
+  for (int i = tid; i < 64; i += 256)
+    bq[i] = i < 48 ? qkv_b[(i / 16) * WC + WHD * h + (i % 16)] : qkv_b[WHD * h + (i - 48)] * (0.25f * WMSA_LOG2E);
 }
 
 bool g_wmsa_stamp_enable = false;

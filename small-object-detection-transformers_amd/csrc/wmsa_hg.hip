@@ -40,14 +40,6 @@ constexpr int HG_LDS_INF = HG_VP_OFF, HG_LDS_SAVE = HG_VP_OFF + 8 * 1024;
 static_assert(HG_LDS_SAVE <= 160 * 1024, "LDS budget");
 static_assert(WL<bf16>::STAGE == 24576 && WL<bf16>::BIAS_OFF == HG_HEADW && WL<bf16>::BQKV_OFF == HG_HEADW + 1920, "pack layout");
 
-typedef __attribute__((ext_vector_type(2))) float f32x2_;
-// a - b on two f32 lanes in one VALU slot (hipcc scalarises a vector subtraction whose results feed v_exp_f32)
-__device__ __forceinline__ f32x2_ pk_sub(const f32x2_& a, const f32x2_& b) {
-  f32x2_ r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
 // STAMP: diagnostic build (sodt_debug_wmsa_hg_stamps): wave 0 of every workgroup sums shader cycles per phase
 __device__ long long g_hg_stamps[512][12];     // rows 0..255: wave 0 (window A, older), 256..511: wave 4 (window B, same SIMD)
 __device__ __forceinline__ long long hg_now() {
@@ -55,6 +47,12 @@ __device__ __forceinline__ long long hg_now() {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
+// census build (tools/valu_census.py, -DSODT_HG_MARK): phase markers in the assembly, no instruction
+#ifdef SODT_HG_MARK
+#define HG_MARK(name) asm volatile("; HGMARK " name)
+#else
+#define HG_MARK(name) do {} while (0)
+#endif
 #define HG_STAMP(i) do { if constexpr (STAMP) { const long long now_ = hg_now(); acc_st[i] += now_ - last_st; last_st = now_; } } while (0)
 
 template <bool SAVE, bool STAMP = false>
@@ -115,33 +113,42 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
   for (int i = tid; i < 5 * WC / 4; i += 512) ((float4*)(smem + HG_LNV_OFF))[i] = ((const float4*)(a.wpk + L::TAIL_OFF))[i];
 
   const int npairs = (a.nwin + 1) / 2;
-  // token-major phases: this lane's row (token 16 j + t of the window) and its six chunks 4 i + g
-  auto row_of = [&](int pair) {
+  // Token-major phases (LN1 prologue, attention-output save, residual + LN2 epilogue): EIGHT lanes per token row.  Wave j owns
+  // tile rows 16 j .. 16 j + 15 as two half-groups hh = 0, 1 of eight rows; lane (r8 = lane >> 3, c8 = lane & 7) holds chunks
+  // c8 + 8 i (i = 0..2) of row 16 j + 8 hh + r8.  One global load / store instruction then moves 8 rows x 128 contiguous bytes -
+  // whole cache lines (the 8 tokens of a half-group are one window row: consecutive token rows in memory) - instead of round
+  // 3's 16 rows x 64 bytes: half the line requests in the CU's address path for the same bytes.  Register index: 3 hh + i.
+  auto row_of = [&](int pair, int hh) {
     int item = 2 * pair + ww;
     if (item >= a.nwin) item = a.nwin - 1;
     const int wx_ = item % a.nwx; item /= a.nwx;
     const int wy_ = item % a.nwy; const int b_ = item / a.nwy;
-    return (unsigned)wtoken(a, b_, wy_, wx_, 16 * j + t);
+    return (unsigned)wtoken(a, b_, wy_, wx_, 16 * j + 8 * hh + (lane >> 3));
   };
   uint4 xc[6], xnext[6];      // x of this wave's 16 tokens: the current pair's (LN1 input AND residual) and the next pair's
   if ((int)blockIdx.x < npairs) {
-    const unsigned ro = row_of(blockIdx.x) * (unsigned)ROWB + (unsigned)(g * 16);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) xc[i] = *(const uint4*)(a.x + (ro + 64u * i));
+    for (int hh = 0; hh < 2; ++hh) {
+      const unsigned ro = row_of(blockIdx.x, hh) * (unsigned)ROWB + (unsigned)((lane & 7) * 16);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xc[3 * hh + i] = *(const uint4*)(a.x + (ro + 128u * i));
+    }
   }
   // Per-lane addresses of the token-major phases, the tile hand-overs and the output rows are re-derived from a LAUNDERED lane
   // id where they are used: as loop invariants they would stay live across the head steps - hipcc spills them - while
   // re-deriving costs a few VALU instructions per window pair.
-  // token-major phases: this lane's LDS row (token 16 j + t of the window), chunk 4 i + g: even i at +64 b, odd i at -64 b (+ 64 i)
+  // LDS: chunk c of tile row r sits at position c ^ (r & 7) (r & 7 = r8 here): lane base + 8 hh rows + 128 i bytes
 #define HG_TOKEN_PTRS()                                                                                   \
   int ll_ = lane; LAUNDER(ll_);                                                                           \
-  const int tl = ll_ & 15, gl = ll_ >> 4;                                                                 \
-  const unsigned trow_ = tile + (unsigned)((16 * j + tl) * ROWB) + (unsigned)((gl ^ (tl & 3)) << 4);      \
-  const unsigned swb_ = (unsigned)(((tl >> 2) & 1) * 64);                                                 \
-  lds_u8* const p_rE = sm3 + trow_ + swb_; lds_u8* const p_rO = sm3 + trow_ - swb_;                       \
-  lds_u8* const p_ln = sm3 + HG_LNV_OFF + gl * KPL * 4;                                                   \
-  const unsigned myrow = (unsigned)wtoken(a, b, wy, wx, 16 * j + tl);                                     \
-  const unsigned myoff = myrow * (unsigned)ROWB + (unsigned)(gl * 16)
+  const int r8 = ll_ >> 3, c8 = ll_ & 7;                                                                  \
+  lds_u8* const p_t0 = sm3 + tile + (unsigned)((16 * j + r8) * ROWB) + (unsigned)((c8 ^ r8) << 4);       \
+  lds_u8* const p_ln = sm3 + HG_LNV_OFF + c8 * KPL * 4;                                                   \
+  const unsigned myrow0 = (unsigned)wtoken(a, b, wy, wx, 16 * j + r8);                                    \
+  const unsigned myrow1 = (unsigned)wtoken(a, b, wy, wx, 16 * j + 8 + r8);                                \
+  const unsigned myoff0 = myrow0 * (unsigned)ROWB + (unsigned)(c8 * 16);                                  \
+  const unsigned myoff1 = myrow1 * (unsigned)ROWB + (unsigned)(c8 * 16)
+#define HG_TPTR(hh, i) (p_t0 + (hh) * 8 * ROWB + 128 * (i))
+#define HG_GOFF(hh, i) (((hh) ? myoff1 : myoff0) + 128u * (i))
   // bias tables of this wave's heads 4 step + j: one base per lane, the step is an immediate offset
   const unsigned tbl = smem0 + HG_TAB_OFF + (unsigned)(j * HG_TABH);
   const unsigned bb3 = tbl + (unsigned)bias_lane_off - (unsigned)(3 * 2 * 16 * E);
@@ -151,6 +158,7 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
   if constexpr (STAMP) last_st = hg_now();
 
   for (int it = blockIdx.x; it < npairs; it += gridDim.x) {
+    HG_MARK("pair-setup");
     int item = 2 * it + ww;
     const bool valid = item < a.nwin;
     if (!valid) item = a.nwin - 1;
@@ -173,53 +181,67 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
     }
 
     // ================= prologue: LN1 of this wave's 16 tokens -> tile rows 16 j .. 16 j + 15
+    HG_MARK("LN1");
     {
       HG_TOKEN_PTRS();
-      float s = 0.f;
+      // x is unpacked once and the statistics are taken in one pass (sum and sum of squares; f32, 192 values of O(1..10): the
+      // cancellation in E[x^2] - mean^2 is ~1e-6 relative, far inside bf16's tolerance): 2 VALU slots per element for the
+      // statistics and 2 FMAs for the normalisation instead of round 3's three passes
+      // x is unpacked once and the statistics are taken in one pass (sum and sum of squares; f32, 192 values of O(1..10): the
+      // cancellation in E[x^2] - mean^2 is ~1e-6 relative, far inside bf16's tolerance): 2 VALU slots per element for the
+      // statistics and 2 FMAs for the normalisation instead of round 3's three passes
+      float f[6][KPL];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        float f[KPL];
-        unpack<T>(xc[i], f);
+      for (int hh = 0; hh < 2; ++hh) {
+        float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int k = 0; k < KPL; ++k) s += f[k];
+        for (int i = 0; i < 3; ++i) {
+          unpack<T>(xc[3 * hh + i], f[3 * hh + i]);
+#pragma unroll
+          for (int k = 0; k < KPL; ++k) { s += f[3 * hh + i][k]; q = fmaf(f[3 * hh + i][k], f[3 * hh + i][k], q); }
+        }
+        s = group8_sum(s);
+        q = group8_sum(q);
+        const float mu = s * (1.0f / WC);
+        const float rstd = rsqrtf(fmaxf(q * (1.0f / WC) - mu * mu, 0.f) + 1e-5f);
+        const float nmr = -mu * rstd;
+        if (SAVE && valid && c8 == 0) *(float2*)((unsigned char*)a.st1 + (hh ? myrow1 : myrow0) * 8u) = make_float2(mu, rstd);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < KPL; ++k) f[3 * hh + i][k] = fmaf(f[3 * hh + i][k], rstd, nmr);
       }
-      s = rows_sum(s);
-      const float mu = s * (1.0f / WC);
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        float f[KPL];
-        unpack<T>(xc[i], f);
-#pragma unroll
-        for (int k = 0; k < KPL; ++k) { const float d = f[k] - mu; q = fmaf(d, d, q); }
-      }
-      q = rows_sum(q);
-      const float rstd = rsqrtf(q * (1.0f / WC) + 1e-5f);
-      if (SAVE && valid && gl == 0) *(float2*)((unsigned char*)a.st1 + myrow * 8u) = make_float2(mu, rstd);
       wave_sync();                                       // this wave's epilogue reads of the same rows are done
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        float ga[KPL], be[KPL], f[KPL];
+      for (int i = 0; i < 3; ++i) {
+        float ga[KPL], be[KPL];
 #pragma unroll
         for (int k = 0; k < KPL; k += 4) {
-          *(f32x4*)(ga + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (WC + 4 * i * KPL + k) * 4);
-          *(f32x4*)(be + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (2 * WC + 4 * i * KPL + k) * 4);
+          *(f32x4*)(ga + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (WC + 64 * i + k) * 4);
+          *(f32x4*)(be + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (2 * WC + 64 * i + k) * 4);
         }
-        unpack<T>(xc[i], f);
 #pragma unroll
-        for (int k = 0; k < KPL; ++k) f[k] = fmaf((f[k] - mu) * rstd, ga[k], be[k]);
-        const uint4 y = pack<T>(f);
-        *(__attribute__((address_space(3))) u32x4_*)(((i & 1) ? p_rO : p_rE) + 64 * i) = u32x4_{y.x, y.y, y.z, y.w};
-        if (SAVE && valid) *(uint4*)(a.xn1 + (myoff + 64u * i)) = y;
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+          for (int k = 0; k < KPL; ++k) f[3 * hh + i][k] = fmaf(f[3 * hh + i][k], ga[k], be[k]);
+          const uint4 y = pack<T>(f[3 * hh + i]);
+          *(__attribute__((address_space(3))) u32x4_*)HG_TPTR(hh, i) = u32x4_{y.x, y.y, y.z, y.w};
+          if (SAVE && valid) *(uint4*)(a.xn1 + HG_GOFF(hh, i)) = y;
+        }
       }
     }
     // W(0) was requested before the previous pair's epilogue stores (or at kernel start): everything older than the
     // youngest stores has landed.  The stores themselves stay in flight.
     HG_STAMP(0);
-    // (inference: the 12 x_mid / xn2 stores of the previous pair; training: + its LN2 statistics and this pair's LN1 statistics
-    //  and xn1 rows, 20 in all - a wave of a clamped tail window issued fewer and waits for everything)
+    // The count is the number of store INSTRUCTIONS this wave has issued since that request, all of them under `valid` and none
+    // under a lane-dependent branch that could skip the instruction (the c8 == 0 statistics stores keep 8 lanes active):
+    //   inference: x_mid 6 + xn2 6 of the previous pair                                                           = 12
+    //   training:  LN2 statistics 2 + x_mid 6 + xn2 6 of the previous pair, LN1 statistics 2 + xn1 6 of this pair = 22
+    // A smaller number than the stores really in flight only waits longer; a larger one would let QKV read a half-landed weight
+    // buffer - tests/test_wmsa_block_gpu.py runs geometries with several pairs per workgroup (and a clamped tail: that wave
+    // issued fewer stores and waits for everything) in both forms against the float64 reference.
     if (!SAVE) HG_VMWAIT(12);
-    else if (valid) HG_VMWAIT(20);
+    else if (valid) HG_VMWAIT(22);
     else HG_VMWAIT(0);
     __syncthreads();                                     // B1: tiles complete, W(0) visible
     HG_STAMP(1);
@@ -231,7 +253,8 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
       constexpr int TBO = step * 4 * HG_TABH;            // table / bias of head 4 step + j relative to the lane bases
       typedef typename KR<T>::type kreg_t;
       // ---- q^T, k^T (channel rows, token columns) and v (token rows, channel columns) of head h
-      u32x4_ bqr = lds_rd128a<TBO>(sbg), bkr = lds_rd128a<TBO + 64>(sbg);
+      HG_MARK("QKV");
+      u32x4_ bqr = lds_rd128a<TBO + 192>(sbg), bkr = lds_rd128a<TBO + 64>(sbg);      // (+192: the q bias x hd^-1/2 x log2 e)
       unsigned bvr = lds_rd32a<TBO + 128>(sbt);
       // fragments are single-buffered: the reads of k-step kk + 1 are issued right after the MFMAs of k-step kk (which
       // have taken their operands) and land while those execute; the SIMD's second wave fills what is left of the gap
@@ -271,13 +294,16 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
         }
         if constexpr (kk + 1 < 6) issue_k(std::integral_constant<int, kk + 1>{});
       });
+      HG_MARK("QKV-post");
       // the head's bias-table entries (7 x 4 per lane): requested now, used after the hand-over barrier
       kreg_t biar[7];
       static_for<0, 7>([&](auto d_) { constexpr int d = decltype(d_)::value; biar[d] = KR<T>::template rd<TBO + d * 2 * 16 * E>(bb3); });
+      // hd^-1/2 x log2 e is folded into the packed Wq / q bias (sodt_wmsa_pack): q^T leaves the MFMAs scaled and S^T ready for
+      // exp2; the q saved for the backward is the reference's unscaled one
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms) {
-        if (SAVE) pq[ms] = pk16<T>(qT[ms]);
-        pqs[ms] = pk16<T>(qT[ms] * scale2);              // hd^-1/2 x log2 e folded into q: S^T leaves the MFMA ready for exp2
+        if (SAVE) pq[ms] = pk16<T>(qT[ms] * (1.0f / scale2));
+        pqs[ms] = pk16<T>(qT[ms]);
         pkk[ms] = pk16<T>(kT[ms]); pv[ms] = pk16<T>(vv[ms]);
       }
       HG_STAMP(2);
@@ -310,47 +336,74 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
       }
 
       HG_STAMP(4);
-      auto body = [&](auto MSK_) {
-        constexpr bool MSK = decltype(MSK_)::value;
+      // Softmax of S^T (already in log2 units: bias x log2 e is the accumulator's initial value).  FAST form: no row maximum -
+      // softmax is shift invariant and f32 / bf16 carry exp2(s) for |s| < 100 (|score| < 69 nats) without over- or underflow -
+      // and the row sums come out of the matrix pipe (an all-ones A operand against the packed P^T the PV product consumes:
+      // every accumulator row holds the sum of its query column), so a strip costs 16 v_exp + 8 v_cvt_pk instead of ~100 VALU
+      // slots.  A row whose sum leaves [1e-30, 1e30] (or is NaN) sends the WAVE through the EXACT form below (row maximum
+      // subtracted, VALU sums: round 3's body) - wave-uniform, no barrier inside; tests force it with large logits.
+      auto body = [&](auto MSK_, auto EXACT_) -> bool {
+        constexpr bool MSK = decltype(MSK_)::value, EXACT = decltype(EXACT_)::value;
+        if constexpr (EXACT) HG_MARK("softmax-exact(cold)"); else if constexpr (MSK) HG_MARK("softmax+PV masked"); else HG_MARK("softmax+PV");
         // ---- S^T = K Q^T: row = key 16 ks + 4 g + r, column = query 16 ms + t; the bias is the accumulator's initial value
         f32x4 bia[7];
-        LDS_WAIT(0);
+        if constexpr (!EXACT) LDS_WAIT(0);
 #pragma unroll
-        for (int d = 0; d < 7; ++d) { LDS_DEP(biar[d]); bia[d] = KR<T>::f4(biar[d]); }
+        for (int d = 0; d < 7; ++d) { if constexpr (!EXACT) LDS_DEP(biar[d]); bia[d] = KR<T>::f4(biar[d]); }
         k16_t pp[4][4];                                  // P^T strips, packed: [ks][ms]
         float inv[4];
+        float lsel = 0.f;
+        bool bad = false;
+        const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
           f32x4 s[4];
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) { s[ks] = bia[ms - ks + 3]; mmak16(s[ks], pkk[ks], pqs[ms]); }
-          float mx = -1e30f;
+          if constexpr (MSK) {
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if constexpr (MSK) { if ((diffm[ms] >> (4 * ks + r)) & 1u) s[ks][r] += -100.0f * WMSA_LOG2E; }
-              mx = fmaxf(mx, s[ks][r]);
-            }
-          mx = rows_max(mx);
-          // (vector forms: hipcc turns the subtraction and the running sums into v_pk_add_f32, two elements per VALU slot -
-          //  the SIMD issues one wave64 f32 instruction per 4 cycles whatever the number of waves)
-          f32x4 sum4 = f32x4{0.f, 0.f, 0.f, 0.f};
-          const f32x2_ mx2 = f32x2_{mx, mx};
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const f32x2_ d0 = pk_sub(f32x2_{s[ks][0], s[ks][1]}, mx2), d1 = pk_sub(f32x2_{s[ks][2], s[ks][3]}, mx2);
-            s[ks] = f32x4{__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1]), __builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
-            sum4 += s[ks];
-            pp[ks][ms] = pk16<T>(s[ks]);
+              for (int r = 0; r < 4; ++r)
+                if ((diffm[ms] >> (4 * ks + r)) & 1u) s[ks][r] += -100.0f * WMSA_LOG2E;
           }
-          float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
-          sum = rows_sum(sum);
+          float sum, lsev;
+          if constexpr (EXACT) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[ks][r]);
+            mx = rows_max(mx);
+            f32x4 sum4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              s[ks] = f32x4{__builtin_amdgcn_exp2f(s[ks][0] - mx), __builtin_amdgcn_exp2f(s[ks][1] - mx),
+                            __builtin_amdgcn_exp2f(s[ks][2] - mx), __builtin_amdgcn_exp2f(s[ks][3] - mx)};
+              sum4 += s[ks];
+              pp[ks][ms] = pk16<T>(s[ks]);
+            }
+            sum = rows_sum((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));
+            lsev = mx * (1.0f / WMSA_LOG2E) + __logf(sum);
+          } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              s[ks] = f32x4{__builtin_amdgcn_exp2f(s[ks][0]), __builtin_amdgcn_exp2f(s[ks][1]),
+                            __builtin_amdgcn_exp2f(s[ks][2]), __builtin_amdgcn_exp2f(s[ks][3])};
+              pp[ks][ms] = pk16<T>(s[ks]);
+            }
+            f32x4 sa = mma16z<bf16>(ones, make_uint4(pp[0][ms].x, pp[0][ms].y, pp[1][ms].x, pp[1][ms].y));
+            mma16<bf16>(sa, ones, make_uint4(pp[2][ms].x, pp[2][ms].y, pp[3][ms].x, pp[3][ms].y));
+            sum = sa[0];
+            bad |= !(sum > 1e-30f && sum < 1e30f);
+            lsev = __logf(sum);
+            if (ms < 3) dma_part(step + 1, 3 + 2 * ms, 5 + 2 * ms);       // (issued once: the exact form runs after the fast one)
+          }
           inv[ms] = __builtin_amdgcn_rcpf(sum);
-          if (ms < 3) dma_part(step + 1, 3 + 2 * ms, 5 + 2 * ms);
-          if (SAVE && valid && g == 0)
-            (a.lsew + (size_t)(whoff + h) * 64)[16 * ms + t] = mx * (1.0f / WMSA_LOG2E) + __logf(sum);
+          if (SAVE) lsel = g == ms ? lsev : lsel;          // every row group holds the query's sum: group g keeps strip g
         }
+        // log-sum-exp of the head's 64 queries: ONE 256-byte store (lane (g, t) <-> query 16 g + t) instead of four 64-byte ones
+        if (SAVE && valid) (a.lsew + (size_t)(whoff + h) * 64)[lane] = lsel;
         // ---- O^T = V^T P^T: row = channel 4 g + r, column = query
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
@@ -362,10 +415,17 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
           o *= inv[ms];
           poall[step][ms] = pk16<T>(o);
         }
+        return bad;
       };
-      if (msk) body(std::true_type{}); else body(std::false_type{});
+      {
+        const bool bad = msk ? body(std::true_type{}, std::false_type{}) : body(std::false_type{}, std::false_type{});
+        if (__builtin_expect(__ballot(bad) != 0ull, 0)) {
+          if (msk) body(std::true_type{}, std::true_type{}); else body(std::false_type{}, std::true_type{});
+        }
+      }
       HG_STAMP(5);
 
+      HG_MARK("step-end");
       if constexpr (step < 2) {
         HG_VMWAIT(0);                                    // this wave's pieces of the next weights have landed
         __syncthreads();                                 // B3/5
@@ -373,6 +433,7 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
       }
     });
 
+    HG_MARK("O->tile");
     // ================= O^T of this wave's three heads -> the (dead) LN1 tile, now the attention-output tile [64][192]
     // (every wave passed B6 after its last QKV phase: nobody reads LN1 rows any more)
     {
@@ -391,12 +452,28 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
     __syncthreads();                                     // B7: attention-output tiles complete, Wproj visible
     HG_STAMP(7);
 
+    // x rows of the next pair: requested here, ahead of the projection (1.7 - 2.4 K cycles of matrix work cover a good part of
+    // the HBM round trip; round 3 requested them next to the W(0) copy after the projection and then sat in the staging phase
+    // for ~9 K cycles) and ahead of this phase's stores
+    const bool more = it + (int)gridDim.x < npairs;
+    {
+      const int nx = it + (int)gridDim.x < npairs ? it + (int)gridDim.x : it;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const unsigned ro = row_of(nx, hh) * (unsigned)ROWB + (unsigned)((lane & 7) * 16);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xnext[3 * hh + i] = *(const uint4*)(a.x + (ro + 128u * i));
+      }
+    }
     if (SAVE && valid) {                                 // attention output, natural token order (operand of the dWproj GEMM)
       HG_TOKEN_PTRS();
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
-        *(uint4*)(a.ao + (myoff + 64u * i)) = u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)(((i & 1) ? p_rO : p_rE) + 64 * i));
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          *(uint4*)(a.ao + HG_GOFF(hh, i)) = u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)HG_TPTR(hh, i));
     }
+    HG_MARK("projection");
     // ================= output projection: out^T rows 48 j .. 48 j + 47 (three 16-row strips) x 64 tokens, K = 192
     f32x4 oT[3][4];
     {
@@ -442,15 +519,9 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
     __syncthreads();                                     // B8: everyone is done with the attention-output tile and Wproj
     HG_STAMP(9);
 
-    // the first weights and the x rows of the next pair: requested before the output stores (a load queued behind a store
-    // waits for the store's acknowledgement), consumed by the next prologue
-    const bool more = it + (int)gridDim.x < npairs;
-    {
-      const int nx = it + (int)gridDim.x < npairs ? it + (int)gridDim.x : it;
-      const unsigned ro = row_of(nx) * (unsigned)ROWB + (unsigned)(g * 16);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) xnext[i] = *(const uint4*)(a.x + (ro + 64u * i));
-    }
+    HG_MARK("staging");
+    // the first weights of the next pair: requested before the output stores (a load queued behind a store waits for the
+    // store's acknowledgement), consumed by the next prologue
     // out^T (+ bias) -> tile, run dtype: the rounding a separate projection launch applies to its output
     {
       int ll_ = lane; LAUNDER(ll_);
@@ -472,47 +543,61 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
     HG_STAMP(10);
 
     // ================= epilogue: x_mid = x + (out + bproj), xn2 = LN2(x_mid) for this wave's 16 tokens
+    HG_MARK("epilogue");
     {
       HG_TOKEN_PTRS();
       float v[6][KPL];
-      float s = 0.f;
+      uint4 xmp[6];                                      // x_mid in bf16: what is stored, and what LN2 normalises
+      float mu2[2], rs2[2];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        float f[KPL], o[KPL];
-        unpack<T>(xc[i], f);                             // residual: the x this wave loaded for LN1, still in registers
-        unpack<T>(u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)(((i & 1) ? p_rO : p_rE) + 64 * i)), o);
-        // x_mid is stored in bf16: LN2 normalises the ROUNDED value, as a separate LayerNorm launch reading x_mid would
+      for (int hh = 0; hh < 2; ++hh) {
+        float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int k = 0; k < KPL; ++k) { v[i][k] = to_f(from_f<T>(f[k] + o[k])); s += v[i][k]; }
+        for (int i = 0; i < 3; ++i) {
+          float f[KPL], o[KPL];
+          unpack<T>(xc[3 * hh + i], f);                  // residual: the x this wave loaded for LN1, still in registers
+          unpack<T>(u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)HG_TPTR(hh, i)), o);
+          // x_mid is stored in bf16: LN2 normalises the ROUNDED value, as a separate LayerNorm launch reading x_mid would
+#pragma unroll
+          for (int k = 0; k < KPL; ++k) f[k] += o[k];
+          xmp[3 * hh + i] = pack<T>(f);
+          unpack<T>(xmp[3 * hh + i], v[3 * hh + i]);
+#pragma unroll
+          for (int k = 0; k < KPL; ++k) { s += v[3 * hh + i][k]; q = fmaf(v[3 * hh + i][k], v[3 * hh + i][k], q); }
+        }
+        s = group8_sum(s);
+        q = group8_sum(q);
+        mu2[hh] = s * (1.0f / WC);
+        rs2[hh] = rsqrtf(fmaxf(q * (1.0f / WC) - mu2[hh] * mu2[hh], 0.f) + 1e-5f);
       }
-      s = rows_sum(s);
-      const float mu = s * (1.0f / WC);
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int k = 0; k < KPL; ++k) { const float d = v[i][k] - mu; q = fmaf(d, d, q); }
-      q = rows_sum(q);
-      const float rs = rsqrtf(q * (1.0f / WC) + 1e-5f);
 #ifdef SODT_HG_ABLATE_STORES   // timing-only A/B build (tools/exp/ab_build.sh): never defined in the library build
       if (false) {
 #else
       if (valid) {
 #endif
-        if (SAVE && gl == 0) *(float2*)((unsigned char*)a.st2 + myrow * 8u) = make_float2(mu, rs);
+        if (SAVE && c8 == 0) {
+          *(float2*)((unsigned char*)a.st2 + myrow0 * 8u) = make_float2(mu2[0], rs2[0]);
+          *(float2*)((unsigned char*)a.st2 + myrow1 * 8u) = make_float2(mu2[1], rs2[1]);
+        }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) *(uint4*)(a.xm + (myoff + 64u * i)) = pack<T>(v[i]);
+        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          float f[KPL], ga[KPL], be[KPL];
+          for (int i = 0; i < 3; ++i) *(uint4*)(a.xm + HG_GOFF(hh, i)) = xmp[3 * hh + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          float ga[KPL], be[KPL];
 #pragma unroll
           for (int k = 0; k < KPL; k += 4) {
-            *(f32x4*)(ga + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (3 * WC + 4 * i * KPL + k) * 4);
-            *(f32x4*)(be + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (4 * WC + 4 * i * KPL + k) * 4);
+            *(f32x4*)(ga + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (3 * WC + 64 * i + k) * 4);
+            *(f32x4*)(be + k) = *(const __attribute__((address_space(3))) f32x4*)(p_ln + (4 * WC + 64 * i + k) * 4);
           }
 #pragma unroll
-          for (int k = 0; k < KPL; ++k) f[k] = fmaf((v[i][k] - mu) * rs, ga[k], be[k]);
-          *(uint4*)(a.xn2 + (myoff + 64u * i)) = pack<T>(f);
+          for (int hh = 0; hh < 2; ++hh) {
+            const float nmr = -mu2[hh] * rs2[hh];
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) v[3 * hh + i][k] = fmaf(fmaf(v[3 * hh + i][k], rs2[hh], nmr), ga[k], be[k]);
+            *(uint4*)(a.xn2 + HG_GOFF(hh, i)) = pack<T>(v[3 * hh + i]);
+          }
         }
       } else {
         HG_VMWAIT(0);                                    // (no stores were issued: the counted wait of the next prologue must not run short)
@@ -522,6 +607,7 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
     for (int i = 0; i < 6; ++i) xc[i] = xnext[i];
     HG_STAMP(11);
   }
+  HG_MARK("exit");
   HG_VMWAIT(0);
   if constexpr (STAMP) {
     if ((tid == 0 || tid == 256) && blockIdx.x < 256)

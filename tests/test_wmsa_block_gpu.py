@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 C, HEADS, WS, HD = 192, 12, 8, 16
 
 
-def _params(dev, seed=0):
+def _params(dev, seed=0, qk_scale=1.0):
     g = torch.Generator(device="cpu").manual_seed(seed)
 
     def r(*shape, scale=1.0):
@@ -21,6 +21,9 @@ def _params(dev, seed=0):
           "attn.qkv.weight": r(3 * C, C, scale=1.5 / C ** 0.5), "attn.qkv.bias": r(3 * C, scale=0.2),
           "attn.proj.weight": r(C, C, scale=1.5 / C ** 0.5), "attn.proj.bias": r(C, scale=0.2),
           "attn.relative_position_bias_table": r((2 * WS - 1) ** 2, HEADS, scale=0.7)}
+    if qk_scale != 1.0:            # large attention logits: q and k rows of the fused qkv projection scaled up
+        sd["attn.qkv.weight"][:2 * C] *= qk_scale
+        sd["attn.qkv.bias"][:2 * C] *= qk_scale
     return sd
 
 
@@ -120,11 +123,55 @@ def test_wmsa_block_forward_and_saved_tensors(ops, dev, dt, B, H, W, shift):
     st2_ref = torch.stack((xm_k.mean(-1), (xm_k.var(-1, unbiased=False) + 1e-5).rsqrt()), -1)
     e, s = _err(outs["st2"], st2_ref)
     assert e <= 2e-4 * max(s, 1.0), f"st2: {e:.3e}"
-    # inference form: no saved tensors, same x_mid / xn2 bit for bit
+    # inference form: no saved tensors; against the reference first (so a wrong inference build is told from a wrong training
+    # build), then bit for bit against the training form (same arithmetic)
     xm2, xn22 = torch.zeros_like(outs["xm"]), torch.zeros_like(outs["xn2"])
     ops.wmsa_block_fwd(x, wpk, xm2, xn22, None, None, None, None, None, None, B, H, W, C, HEADS, WS, shift)
     torch.cuda.synchronize()
-    assert torch.equal(xm2, outs["xm"]) and torch.equal(xn22, outs["xn2"])
+    e, s = _err(xm2, ref["xm"])
+    assert e <= tol * max(s, 1.0), f"inference-form xm: max err {e:.3e} (scale {s:.3e}, {dt}, shift {shift})"
+    nd = int((xm2 != outs["xm"]).sum()) + int((xn22 != outs["xn2"]).sum())
+    assert nd == 0, f"inference and training form differ in {nd} of {2 * xm2.numel()} elements"
+
+
+@pytest.mark.parametrize("qk_scale", [3.0, 12.0])
+def test_wmsa_softmax_range_guard(ops, dev, qk_scale):
+    """The bf16 kernel's softmax takes exp2 of the logits WITHOUT subtracting the row maximum and checks every row sum against
+    [1e-30, 1e30]; a wave with a row outside re-runs the head through the exact (max-subtracted) form.  Logits scaled up by
+    9x (some waves of the launch fall back, others do not) and 144x (exp2 overflows everywhere: every wave falls back) must
+    still match the float64 reference - rare data-dependent branch, forced here (cdna_hip_programming.md rule 26)."""
+    import importlib
+    L = importlib.import_module("small-object-detection-transformers_amd._lib")
+    B, H, W, shift, dt = 2, 16, 24, 2, torch.bfloat16
+    sd = _params(dev, seed=41, qk_scale=qk_scale)
+    M = B * H * W
+    gx = torch.Generator(device="cpu").manual_seed(9)
+    x = (torch.randn(M, C, generator=gx) * 1.3 + 0.2).to(dev).to(dt)
+    sdr = {k: (v.to(dt).float() if v.dim() == 2 and "table" not in k else v) for k, v in sd.items()}
+    ref = _reference(sdr, x.float(), B, H, W, shift)
+    lmax = float(ref["lse"].abs().max())
+    assert lmax > (60.0 if qk_scale < 5 else 500.0), lmax          # the logits really leave the fast form's range
+    wpk = _pack(ops, L, sd, dev, dt)
+    nwin = M // 64
+    outs = dict(xm=torch.zeros(M, C, device=dev, dtype=dt), xn2=torch.zeros(M, C, device=dev, dtype=dt),
+                st1=torch.zeros(M, 2, device=dev), st2=torch.zeros(M, 2, device=dev),
+                xn1=torch.zeros(M, C, device=dev, dtype=dt), qkvw=torch.zeros(nwin, HEADS, 3, 64, HD, device=dev, dtype=dt),
+                lse=torch.zeros(nwin, HEADS, 64, device=dev), ao=torch.zeros(M, C, device=dev, dtype=dt))
+    ops.wmsa_block_fwd(x, wpk, outs["xm"], outs["xn2"], outs["st1"], outs["st2"], outs["xn1"], outs["qkvw"], outs["lse"],
+                       outs["ao"], B, H, W, C, HEADS, WS, shift)
+    xm2, xn22 = torch.zeros_like(outs["xm"]), torch.zeros_like(outs["xn2"])
+    ops.wmsa_block_fwd(x, wpk, xm2, xn22, None, None, None, None, None, None, B, H, W, C, HEADS, WS, shift)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs["xm"].float()).all()) and bool(torch.isfinite(outs["lse"]).all())
+    # near one-hot attention: a bf16 rounding of q or k can move a logit of magnitude ~lmax by lmax * 2^-8, so the weights of
+    # near-tied keys (and with them ao / xm) move by O(that); lse is compared relative to its size
+    for name, tol in (("xn1", 3e-2), ("qkvw", 3e-2), ("lse", 3e-2)):
+        e, s = _err(outs[name], ref[name])
+        assert e <= tol * max(s, 1.0), f"{name}: max err {e:.3e} (scale {s:.3e})"
+    e, s = _err(outs["ao"], ref["ao"])
+    frac_bad = float(((outs["ao"].double().cpu() - ref["ao"]).abs() > 0.1 * max(s, 1.0)).double().mean())
+    assert frac_bad <= (1e-2 if qk_scale < 5 else 8e-2), f"ao: {frac_bad:.2e} of the elements off by more than 10 % of the scale"
+    assert int((xm2 != outs["xm"]).sum()) == 0
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
