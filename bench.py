@@ -201,11 +201,11 @@ def main():
         kern_ms = sum(s_.elapsed_time(e_) for step_evs in evs for s_, e_ in step_evs) / (len(evs) * len(probe_idx))
         # algorithmic work of one launch: 8 T C^2 + 4 T N C flops with T = B t^2 tokens, C = 192, N = 64
         flops = 8.0 * Mrows * 192 * 192 + 4.0 * Mrows * 64 * 192
-        # algorithmic HBM bytes of one TRAINING launch: x in; x_mid, xn2, xn1, ao, q, k, v out = 8 token rows of C elements
-        # (rounds 1-2 counted 9: one row too many), + log-sum-exp (12 f32) and two (mean, rstd) pairs per token; inference:
-        # x in, x_mid + xn2 out
+        # algorithmic HBM bytes of one TRAINING launch: x in; x_mid, xn2, xn1, ao out = 5 token rows of C elements (bf16, round 4:
+        # q / k / v are no longer saved - the backward recomputes them; the f32 parity kernel still writes them: 8 rows)
+        # + log-sum-exp (12 f32) and two (mean, rstd) pairs per token; inference: x in, x_mid + xn2 out
         es = 2 if a.dtype == "bf16" else 4
-        alg_bytes = Mrows * (8 * 192 * es + 12 * 4 + 16)
+        alg_bytes = Mrows * ((5 if a.dtype == "bf16" else 8) * 192 * es + 12 * 4 + 16)
         achieved = flops / (kern_ms * 1e-3) / 1e12
         traffic, prof = None, None
         pdir = os.path.join(ROOT, "profiles")

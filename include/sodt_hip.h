@@ -151,7 +151,10 @@ int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const void* out, 
  *   outputs (all or none): xn1 = LN1(x) [M][C]; st1 / st2 = (mean, rstd) of LN1 / LN2, f32 [M][2]; ao = attention
  *   output before the projection [M][C]; qkvw = q|k|v in window-major order [window][head][3][64][16] run dtype and
  *   lsew = log-sum-exp [window][head][64] f32, window = (b*(H/8) + wy)*(W/8) + wx in the shifted frame, token =
- *   window-local row-major - the operands of sodt_window_attn_bwd_wm.  Pass xn1 == NULL for inference. */
+ *   window-local row-major - the operands of sodt_window_attn_bwd_wm.  Pass xn1 == NULL for inference.
+ *   bf16: qkvw may be NULL (and the four-waves-per-window kernel never writes it): its backward, sodt_wmsa_block_bwd,
+ *   recomputes q / k / v from xn1 and the pack; a non-NULL qkvw with bf16 returns SODT_EINVAL.  f32 (the parity path)
+ *   requires qkvw. */
 long sodt_wmsa_pack_bytes(int C, int heads, int ws, int dtype);
 int sodt_wmsa_pack(const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b,
                    const float* rpb_table, const float* n1_w, const float* n1_b, const float* n2_w,
@@ -168,6 +171,15 @@ int sodt_debug_wmsa_hg_stamps(long long* out_host_512x12, int enable);
 int sodt_window_attn_bwd_wm(const void* qkvw, const float* bias_t, const void* dout, const float* lsew,
                             void* dqkv, float* dbias_t, int B, int H, int W, int C, int heads, int ws,
                             int shift, int dtype, sodt_stream_t st);
+/* First stage of the fused block's backward, bf16 (backbone_vit.py:968 + the autograd of :971-989): d(attention output) dout
+ * [M][C] -> dqkv [M][3C] and the relative-position-bias gradient dbias_t [heads][(2ws-1)^2] (accumulated), with q / k / v
+ * RECOMPUTED per (window, head) from the block's saved LayerNorm-1 output xn1 [M][C] and its parameter pack wpk
+ * (sodt_wmsa_pack) - the same MFMA product the forward ran - instead of read back from HBM; lsew as written by
+ * sodt_wmsa_block_fwd.  C == 192, heads == 12, ws == 8, dtype == SODT_BF16 only; anything else returns SODT_EINVAL.  The
+ * dgrad / wgrad GEMMs and the LayerNorm backward of the block stay separate launches (sodt_gemm_nt / _tn, sodt_layernorm_bwd). */
+int sodt_wmsa_block_bwd(const void* xn1, const void* wpk, const float* bias_t, const void* dout, const float* lsew,
+                        void* dqkv, float* dbias_t, int B, int H, int W, int C, int heads, int ws, int shift,
+                        int dtype, sodt_stream_t st);
 
 /* Front end (backbone_vit.py:195-210): channel split, 4x Conv2d(1->48,k4,s4) (R with
  * padding 1), pairwise cross-channel attention (R<-G, G<-B, B<-IR, IR<-G; 12 heads x 4,

@@ -87,6 +87,7 @@ SIGNATURES = {
     "sodt_wmsa_pack": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sodt_wmsa_block_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sodt_window_attn_bwd_wm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sodt_wmsa_block_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sodt_frontend_fwd": [_P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sodt_frontend_bwd": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _I, _P],
     "sodt_patch_embed4_fwd": [_P, _P, _L, _P, _P, _P, _I, _I, _P],

@@ -19,6 +19,7 @@
 // small LDS table per head ((2R-1) x (2ws-1) <= 225 entries, R = 64/ws rows per tile)
 // and flushed with a few global atomics.
 #include "common.h"
+#include "wmsa_pack.h"
 #include "../../include/sodt_hip.h"
 #include <type_traits>
 
@@ -1083,11 +1084,18 @@ template <> __device__ __forceinline__ uint4 fragTp<float>(const unsigned char* 
 
 // WM: q / k / v and the log-sum-exp come in the WINDOW-MAJOR layout the fused forward (wmsa_block.hip) saves:
 // qkv = [window][head][q|k|v][64 tokens][HD], lse = [window][head][64] - 2 KB contiguous per tensor, window and head.
-template <typename T, int HD, int NW, bool WM = false>
+// RC (bf16, HD 16, NW 4; implies window-major lse): q / k / v are not read at all - `qkv` is the block's saved LayerNorm-1
+// output xn1 [M][C] (token-major) and `wpk` its parameter pack (sodt_wmsa_pack): each wave recomputes q^T, k^T, v^T of its head
+// for the window by MFMA (72 per window and head) from the window's xn1 tile in LDS and the head's weight fragments streamed
+// from L2, exactly as the fused forward computed them, and writes them into the Q / K / V tiles the body reads.  The fused
+// forward then saves no q / k / v (604 of its 1,644 MB per stage-1 launch); this kernel reads 201 MB (one pass over xn1 per
+// head group: three workgroups walk the same windows, the second and third read is served by L2) instead of 604 MB.
+template <typename T, int HD, int NW, bool WM = false, bool RC = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_t,
                                                                 const T* __restrict__ d_out, const float* __restrict__ lse,
                                                                 T* __restrict__ dqkv, float* __restrict__ dbias_t,
-                                                                const AttnGeo g, int nwin_total) {
+                                                                const AttnGeo g, int nwin_total, const unsigned char* __restrict__ wpk = nullptr) {
+  static_assert(!RC || (WM && std::is_same<T, bf16>::value && HD == 16 && NW == 4), "RC: bf16, head dim 16, four heads per workgroup");
   using L = Lay<T, HD>;
   constexpr int E = L::E, KPL = L::KPL, NT = NW * 64, CPR = NW * L::DCH, NPF = L::DCH, MK = TT<T>::MMA_K;
   constexpr int SPK = MK / 16;                  // 16-query strips per MFMA k-block: 2 (bf16) or 1 (f32)
@@ -1096,8 +1104,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
   constexpr bool LATE_PF = NW == 4;             // four-head workgroups run two per CU (see the launch bounds)
   __shared__ __attribute__((aligned(16))) unsigned char sQ[NW * L::QTILE], sK[NW * L::QTILE], sV[NW * L::QTILE],
       sDO[NW * L::QTILE];
-  __shared__ __attribute__((aligned(16))) unsigned char sDS[NW * 64 * DSROW];
-  __shared__ __attribute__((aligned(16))) unsigned char sDQ[NW * L::QTILE];      // dQ staging (Q stays live to the end)
+  // dS patches | dQ staging (Q stays live to the end).  RC: the window's xn1 tile ([64][C] bf16, 16-byte chunks XOR-swizzled
+  // with row & 7) lives in the same bytes while q / k / v are recomputed, before the first dS patch is written
+  __shared__ __attribute__((aligned(16))) unsigned char sDSQ[NW * 64 * DSROW + NW * L::QTILE];
+  unsigned char* const sDS = sDSQ;
+  unsigned char* const sDQ = sDSQ + NW * 64 * DSROW;
+  static_assert(!RC || NW * 64 * DSROW + NW * L::QTILE >= 64 * 192 * 2, "xn1 tile fits the dS / dQ area");
   __shared__ float sDB[NW][LTMAX + 3];       // bias values x log2 e during the walk, bias-gradient table at the end
   __shared__ float sLse[NW][64];
   __shared__ int sTokQ[64];
@@ -1109,6 +1121,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
   const int C3 = 3 * g.C, L2 = 2 * g.ws - 1;
   const int R = 64 / g.ws, LT = (2 * R - 1) * L2;
   const float scale = rsqrtf((float)HD), scale2 = scale * SODT_LOG2E;
+  // RC: the Q tile holds q_s = scale2 x q, so the logits need no factor, dK = dS^T q_s / log2 e, and dQ (the gradient of the
+  // UNSCALED q, what the dWqkv / dxn1 GEMMs expect) = scale x dS K as always
+  const float sc_s = RC ? 1.0f : scale2, sc_dk = RC ? (1.0f / SODT_LOG2E) : scale;
   const float* bt = bias_t + (long)head * L2 * L2;
   unsigned char* myQ = sQ + w * L::QTILE; unsigned char* myK = sK + w * L::QTILE;
   unsigned char* myV = sV + w * L::QTILE; unsigned char* myDO = sDO + w * L::QTILE;
@@ -1132,7 +1147,38 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
     bAddr[r] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&sDB[w][(dy0 + 7) * L2 + dx + 7];
   }
   uint4 pq0, pq1, pq2, pq3, pk0, pk1, pk2, pk3, pv0, pv1, pv2, pv3, pd0, pd1, pd2, pd3;
+  uint4 px0, px1, px2, px3, px4, px5;        // RC: this thread's six 16-byte chunks of the next window's xn1 tile
   float plse = 0.f;
+  constexpr int XCH = 24;                    // RC: 16-byte chunks per xn1 row (C = 192 bf16)
+  // RC: thread (r = tid >> 3, c8 = tid & 7) fetches chunks c8, c8 + 8, c8 + 16 of tile rows r and r + 32: eight lanes read 128
+  // contiguous bytes of a token row (whole cache lines), the chunk step is an immediate, and the only per-thread index
+  // state is two token rows per window (six independent (row, chunk) pairs per thread cost ~40 loop-invariant address
+  // registers and put the kernel over its 256-register budget)
+#define B2_ISSUE_XALL(ITEM)                                                             \
+  {                                                                                     \
+    int t_ = (ITEM);                                                                    \
+    const int wx_ = t_ % g.nwx; t_ /= g.nwx;                                            \
+    const int wy_ = t_ % g.nwy; const int b_ = t_ / g.nwy;                              \
+    int tz_ = tid; asm volatile("" : "+v"(tz_));      /* (not loop-invariant for the compiler: re-derived, not spilled) */ \
+    const int r_ = tz_ >> 3;                                                            \
+    int ya = wy_ * 8 + (r_ >> 3) + g.shift, xa = wx_ * 8 + (r_ & 7) + g.shift;          \
+    int yb = ya + 4;                                                                    \
+    if (ya >= g.H) ya -= g.H;                                                           \
+    if (yb >= g.H) yb -= g.H;                                                           \
+    if (xa >= g.W) xa -= g.W;                                                           \
+    const T* sa_ = qkv + ((long)(b_ * g.H + ya) * g.W + xa) * g.C + (tz_ & 7) * KPL;    \
+    const T* sb_ = qkv + ((long)(b_ * g.H + yb) * g.W + xa) * g.C + (tz_ & 7) * KPL;    \
+    px0 = *(const uint4*)(sa_); px1 = *(const uint4*)(sa_ + 8 * KPL); px2 = *(const uint4*)(sa_ + 16 * KPL); \
+    px3 = *(const uint4*)(sb_); px4 = *(const uint4*)(sb_ + 8 * KPL); px5 = *(const uint4*)(sb_ + 16 * KPL); \
+  }
+#define B2_STORE_XALL()                                                                 \
+  {                                                                                     \
+    int tz_ = tid; asm volatile("" : "+v"(tz_));                                        \
+    unsigned char* d_ = sDSQ + (tz_ >> 3) * (XCH * 16) + ((((tz_ & 7) ^ ((tz_ >> 3) & 7))) << 4);   \
+    *(uint4*)(d_) = px0; *(uint4*)(d_ + 128) = px1; *(uint4*)(d_ + 256) = px2;          \
+    d_ += 32 * (XCH * 16);                                                              \
+    *(uint4*)(d_) = px3; *(uint4*)(d_ + 128) = px4; *(uint4*)(d_ + 256) = px5;          \
+  }
 #define B2_ISSUE_ONE(i, ITEM)                                                           \
   if constexpr (NPF > i) {                                                              \
     int t_ = (ITEM);                                                                    \
@@ -1142,7 +1188,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
     const int r = idx / CPR, cc = idx - r * CPR;                                        \
     int row, rid, iy, ix;                                                               \
     win_token(g, b_, wy_, wx_, r, row, rid, iy, ix);                                    \
-    if constexpr (WM) {                                                                 \
+    if constexpr (RC) {                                                                 \
+    } else if constexpr (WM) {                                                          \
       const int h_ = cc / L::DCH, dc_ = cc - h_ * L::DCH;                               \
       const T* src = qkv + (((long)(ITEM) * g.heads + hg * NW + h_) * 3 * 64 + r) * HD + dc_ * KPL; \
       pq##i = *(const uint4*)(src); pk##i = *(const uint4*)(src + 64 * HD); pv##i = *(const uint4*)(src + 2 * 64 * HD); \
@@ -1154,6 +1201,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
   }
 #define B2_ISSUE(ITEM) {                                                                \
     B2_ISSUE_ONE(0, ITEM) B2_ISSUE_ONE(1, ITEM) B2_ISSUE_ONE(2, ITEM) B2_ISSUE_ONE(3, ITEM) \
+    if constexpr (RC) B2_ISSUE_XALL(ITEM)                                               \
     if constexpr (WM) {                                                                 \
       plse = lse[((long)(ITEM) * g.heads + head) * 64 + lane];                          \
     } else {                                                                            \
@@ -1171,7 +1219,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
     const int r = idx / CPR, cc = idx - r * CPR;                                        \
     const int h = cc / L::DCH, dc = cc - h * L::DCH;                                    \
     const int off = (h * 64 + r) * L::QROW + dc * 16;                                   \
-    *(uint4*)(sQ + off) = pq##i; *(uint4*)(sK + off) = pk##i; *(uint4*)(sV + off) = pv##i; *(uint4*)(sDO + off) = pd##i; \
+    if constexpr (!RC) { *(uint4*)(sQ + off) = pq##i; *(uint4*)(sK + off) = pk##i; *(uint4*)(sV + off) = pv##i; } \
+    *(uint4*)(sDO + off) = pd##i;                                                       \
   }
   B2_ISSUE((int)blockIdx.x < nwin_total ? (int)blockIdx.x : 0)
 
@@ -1187,8 +1236,48 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
       sTokQ[tid] = row; sGeoQ[tid][0] = (short)iy; sGeoQ[tid][1] = (short)ix; sGeoQ[tid][2] = (short)rid;
     }
     B2_STORE_ONE(0) B2_STORE_ONE(1) B2_STORE_ONE(2) B2_STORE_ONE(3)
+    if constexpr (RC) B2_STORE_XALL()
     sLse[w][lane] = plse * SODT_LOG2E;
     __syncthreads();
+    if constexpr (RC) {
+      // ---- q^T, k^T, v^T of this wave's head (channel rows 4 fg + r, token columns 16 ms + fr) = W_h xn^T + b: the forward's
+      // own product (backbone_vit.py:968), weights as A fragments straight from the pack (L2-resident: every workgroup of
+      // the head group re-reads the same 72 KB per window), xn^T fragments from the tile
+      // (lane-derived addresses from a laundered lane id: as loop invariants they - and the three bias vectors - would be held
+      //  across the register-heaviest part of the kernel, i.e. spilled)
+      int lz = lane; asm volatile("" : "+v"(lz));
+      const int fr_ = lz & 15, fg_ = lz >> 4;
+      // The forward's OWN operands: its weight stream, where Wq and the q bias carry hd^-1/2 x log2 e (q_s = that scale x q), so
+      // that P = exp2(q_s k + bias - lse) here reproduces the P whose log-sum-exp the forward saved (recomputing an unscaled q
+      // from the unscaled weight copy rounds differently: the logits move by up to 0.05 and the rows of P no longer sum to 1)
+      const unsigned char* wh = wpk + wmsa_pack_bf16::HGW_OFF + (size_t)head * 3 * wmsa_pack_bf16::WFRAG;
+      const float* bqkv = (const float*)(wpk + (size_t)head * wmsa_pack_bf16::STAGE + wmsa_pack_bf16::BQKV_OFF);
+      const f32x4 bq4 = *(const f32x4*)(bqkv + 48 + 4 * fg_), bk4 = *(const f32x4*)(bqkv + 16 + 4 * fg_), bv4 = *(const f32x4*)(bqkv + 32 + 4 * fg_);
+      f32x4 aq[4], ak[4], av[4];
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) { aq[ms] = bq4; ak[ms] = bk4; av[ms] = bv4; }
+      const unsigned char* xl = sDSQ + fr_ * (XCH * 16);
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk) {
+        const uint4 wq = *(const uint4*)(wh + kk * 1024 + lz * 16);
+        const uint4 wk = *(const uint4*)(wh + wmsa_pack_bf16::WFRAG + kk * 1024 + lz * 16);
+        const uint4 wv = *(const uint4*)(wh + 2 * wmsa_pack_bf16::WFRAG + kk * 1024 + lz * 16);
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          const uint4 xf = *(const uint4*)(xl + ms * 16 * (XCH * 16) + (((4 * kk + fg_) ^ (fr_ & 7)) << 4));
+          mma16<bf16>(aq[ms], wq, xf); mma16<bf16>(ak[ms], wk, xf); mma16<bf16>(av[ms], wv, xf);
+        }
+      }
+      // -> the [64 tokens][HD] tiles of this head (this wave's own: no barrier needed before its reads)
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        const int off = (ms * 16 + fr_) * L::QROW + 8 * fg_;
+        *(uint2*)(myQ + off) = make_uint2(pack2bf(aq[ms][0], aq[ms][1]), pack2bf(aq[ms][2], aq[ms][3]));
+        *(uint2*)(myK + off) = make_uint2(pack2bf(ak[ms][0], ak[ms][1]), pack2bf(ak[ms][2], ak[ms][3]));
+        *(uint2*)(myV + off) = make_uint2(pack2bf(av[ms][0], av[ms][1]), pack2bf(av[ms][2], av[ms][3]));
+      }
+      __syncthreads();                                 // every wave is done with the xn1 tile: the dS patches may overwrite it
+    }
     if constexpr (!LATE_PF) {
       const int nxt = item + (int)gridDim.x < nwin_total ? item + (int)gridDim.x : item;
       B2_ISSUE(nxt)
@@ -1240,7 +1329,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
           float dl = 0.f;
 #pragma unroll
           for (int ns = 0; ns < 4; ++ns) {
-            float v = fmaf(s[ns][r], scale2, *(const float*)((const __attribute__((address_space(3))) char*)(uintptr_t)bAddr[r] + 120 * (ms - ns + 3)));
+            float v = fmaf(s[ns][r], sc_s, *(const float*)((const __attribute__((address_space(3))) char*)(uintptr_t)bAddr[r] + 120 * (ms - ns + 3)));
             if constexpr (MSK) { if (qrid != krid[ns]) v += -100.0f * SODT_LOG2E; }
             const float p = fast_exp2(v - lq);
             s[ns][r] = p;
@@ -1312,7 +1401,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) {
           const int off = (i * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E;
-          st_elem<T>(myK + off, dk[i][d][r] * scale);
+          st_elem<T>(myK + off, dk[i][d][r] * sc_dk);
           st_elem<T>(myV + off, dv[i][d][r]);
         }
     __syncthreads();
@@ -1348,6 +1437,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
 #undef B2_ISSUE_ONE
 #undef B2_ISSUE
 #undef B2_STORE_ONE
+#undef B2_ISSUE_XALL
+#undef B2_STORE_XALL
 }
 
 // ---------------------------------------------------------------------------------
@@ -2218,6 +2309,17 @@ int launch_bwd_wm(const void* qkvw, const float* bias_t, const void* dout, const
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
+// the same walk with q / k / v recomputed from the block's saved LN1 output (RC)
+int launch_bwd_rc(const void* xn1, const unsigned char* wpk, const float* bias_t, const void* dout, const float* lsew, void* dqkv,
+                  float* dbias_t, const AttnGeo& g, hipStream_t st) {
+  if (g.heads != 12 || g.C != 192 || g.nqt != 1 || g.ws != 8) return SODT_EINVAL;
+  const int nwin = g.B * g.nwy * g.nwx;
+  const int gx = bwd_persistent_grid(nwin, g.heads / 4, 4);
+  hipLaunchKernelGGL((attn_bwd_fast2_kernel<bf16, 16, 4, true, true>), dim3(gx, g.heads / 4), dim3(256), 0, st,
+                     (const bf16*)xn1, bias_t, (const bf16*)dout, lsew, (bf16*)dqkv, dbias_t, g, nwin, wpk);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
 template <typename T, int HD, int NW>
 int launch_bwd(const void* qkv, const float* bias_t, const void* out, const void* dout, const float* lse, void* dqkv,
                float* dbias_t, float* scratch, const AttnGeo& g, hipStream_t st) {
@@ -2335,4 +2437,17 @@ extern "C" int sodt_window_attn_bwd_wm(const void* qkvw, const float* bias_t, co
   if (dtype == SODT_BF16) return launch_bwd_wm<bf16, 16, 4>(qkvw, bias_t, dout, lsew, dqkv, dbias_t, g, st);
   if (dtype == SODT_F32) return launch_bwd_wm<float, 16, 2>(qkvw, bias_t, dout, lsew, dqkv, dbias_t, g, st);
   return SODT_EINVAL;
+}
+
+/* First stage of the fused W-MSA block's backward (bf16, C = 192, 12 heads, 8x8 windows): d(attention output) -> dqkv and the
+ * relative-position-bias gradient, with q / k / v RECOMPUTED per (window, head) from the block's saved LayerNorm-1 output
+ * `xn1` [M][C] and its parameter pack `wpk` (sodt_wmsa_pack) instead of read back from HBM: the forward (sodt_wmsa_block_fwd
+ * with qkvw = NULL) then saves no q / k / v.  backbone_vit.py:968 (the qkv Linear) + :971-989 (its autograd). */
+extern "C" int sodt_wmsa_block_bwd(const void* xn1, const void* wpk, const float* bias_t, const void* dout, const float* lsew,
+                                   void* dqkv, float* dbias_t, int B, int H, int W, int C, int heads, int ws, int shift,
+                                   int dtype, sodt_stream_t st_) {
+  AttnGeo g;
+  if (!xn1 || !wpk || !bias_t || !dout || !lsew || !dqkv || !dbias_t || !make_geo(g, B, H, W, C, heads, ws, shift)) return SODT_EINVAL;
+  if (dtype != SODT_BF16) return SODT_EINVAL;            // the f32 parity path keeps its saved q / k / v (sodt_window_attn_bwd_wm)
+  return launch_bwd_rc(xn1, (const unsigned char*)wpk, bias_t, dout, lsew, dqkv, dbias_t, g, (hipStream_t)st_);
 }

@@ -690,7 +690,9 @@ extern "C" int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, voi
                                    int B, int H, int W, int C, int heads, int ws, int shift, int dtype, sodt_stream_t st_) {
   if (!x || !wpk || !xm || !xn2 || !wmsa_shape_ok(B, H, W, C, heads, ws, shift)) return SODT_EINVAL;
   const bool save = xn1 != nullptr;
-  if (save && (!qkvw || !lsew || !ao || !st1 || !st2)) return SODT_EINVAL;
+  if (save && (!lsew || !ao || !st1 || !st2)) return SODT_EINVAL;
+  // q / k / v are saved by the f32 parity kernel only: the bf16 backward (sodt_wmsa_block_bwd) recomputes them from xn1
+  if (save && ((dtype == SODT_F32) != (qkvw != nullptr))) return SODT_EINVAL;
   WArgs a;
   a.x = (const unsigned char*)x; a.wpk = (const unsigned char*)wpk;
   a.xm = (unsigned char*)xm; a.xn2 = (unsigned char*)xn2; a.st1 = st1; a.st2 = st2;
@@ -701,7 +703,7 @@ extern "C" int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, voi
     // throughput path: four waves per window (wmsa_hg.hip).  The one-wave-per-window bf16 build below only runs as the
     // instrumented diagnostic build armed through sodt_debug_wmsa_stamps (an explicit API call, no environment switch).
     if (!g_wmsa_stamp_enable) return wmsa_hg_launch(a, save, st);
-    return save ? launch_block<bf16, 4, 2, true, true>(a, st) : launch_block<bf16, 4, 2, false, true>(a, st);
+    return launch_block<bf16, 4, 2, false, true>(a, st);      // (instrumented build: inference form only - its training form writes q / k / v)
   }
   if (dtype == SODT_F32) return save ? launch_block<float, 2, 1, true>(a, st) : launch_block<float, 2, 1, false>(a, st);
   return SODT_EINVAL;

@@ -2,6 +2,7 @@
 // f32 parity path; wmsa_hg.hip: four waves per window, bf16 throughput path).  See wmsa_block.hip for the layouts.
 #pragma once
 #include "common.h"
+#include "wmsa_pack.h"
 #include "../../include/sodt_hip.h"
 #include <type_traits>
 
@@ -56,6 +57,9 @@ template <typename T> struct WL {
   static constexpr int VPB = 64 * WHD * E;               // v transposition patch: 2 KB / 4 KB
 };
 static_assert(WL<bf16>::STAGE == 24576 && WL<float>::STAGE == 49152, "stage layout");
+static_assert(WL<bf16>::STAGE == wmsa_pack_bf16::STAGE && WL<bf16>::WFRAG == wmsa_pack_bf16::WFRAG && WL<bf16>::BQKV_OFF == wmsa_pack_bf16::BQKV_OFF &&
+              WL<bf16>::HGW_OFF == wmsa_pack_bf16::HGW_OFF,
+              "wmsa_pack.h mirrors the bf16 pack layout");
 
 
 // ---- k16 operands: 16 contraction elements per MFMA, lane (g, t) holds k = 4 g + j, j = 0..3

@@ -23,7 +23,7 @@
 //     and q/k/v biases of all 12 heads (26 KB) stay resident.
 //   * ~9 workgroup barriers per window pair; every global store drains in the background (counted vmcnt).
 //
-// LDS: 2 x 24 KB tiles + 72 KB weights + 25.5 KB tables + 3.75 KB vectors (+ 8 KB v patches when saving) = 157.25 KB.
+// LDS: 2 x 24 KB tiles + 72 KB weights + 25.5 KB tables + 3.75 KB vectors = 149.25 KB.
 #include "wmsa_common.h"
 
 namespace {
@@ -35,8 +35,7 @@ constexpr int HG_WBUF = 4 * HG_HEADW;                   // 73728
 constexpr int HG_TAB_OFF = HG_WBUF_OFF + HG_WBUF;       // 122880
 constexpr int HG_TABH = 1920 + 256;                     // table (4 shifted copies) + q/k/v bias of one head
 constexpr int HG_LNV_OFF = HG_TAB_OFF + WHEADS * HG_TABH;   // 148992: bproj | g1 | b1 | g2 | b2 (f32)
-constexpr int HG_VP_OFF = HG_LNV_OFF + 5 * WC * 4;      // 152832: per-wave 1 KB v transposition patch (SAVE)
-constexpr int HG_LDS_INF = HG_VP_OFF, HG_LDS_SAVE = HG_VP_OFF + 8 * 1024;
+constexpr int HG_LDS_INF = HG_LNV_OFF + 5 * WC * 4, HG_LDS_SAVE = HG_LDS_INF;      // 152832 (both forms)
 static_assert(HG_LDS_SAVE <= 160 * 1024, "LDS budget");
 static_assert(WL<bf16>::STAGE == 24576 && WL<bf16>::BIAS_OFF == HG_HEADW && WL<bf16>::BQKV_OFF == HG_HEADW + 1920, "pack layout");
 
@@ -75,7 +74,6 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
   const unsigned xrow = tile + (unsigned)(t * ROWB) + gx3;
   const unsigned xfE = smem0 + xrow + swb, xfO = smem0 + xrow - swb;
   const unsigned wb16 = smem0 + HG_WBUF_OFF + (unsigned)(j * HG_HEADW) + (unsigned)(lane * 16);
-  const float scale2 = 0.25f * WMSA_LOG2E;
   // bias-table addressing of this lane (wmsa_block.hip): four consecutive entries at one aligned address, strip difference 0
   const int j0 = 7 - (t & 7) + 4 * (g & 1), jv = j0 & 3;
   const int bias_lane_off = (((jv * 15 + (t >> 3) - (g >> 1) + 7) * 16) + (j0 - jv)) * E;
@@ -270,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
         });
       };
       issue_k(std::integral_constant<int, 0>{});
-      k16_t pq[4], pqs[4], pkk[4], pv[4];
+      k16_t pqs[4], pkk[4], pv[4];
       f32x4 qT[4], kT[4], vv[4];
       static_for<0, 6>([&](auto kk_) {
         constexpr int kk = decltype(kk_)::value;
@@ -298,11 +296,9 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
       // the head's bias-table entries (7 x 4 per lane): requested now, used after the hand-over barrier
       kreg_t biar[7];
       static_for<0, 7>([&](auto d_) { constexpr int d = decltype(d_)::value; biar[d] = KR<T>::template rd<TBO + d * 2 * 16 * E>(bb3); });
-      // hd^-1/2 x log2 e is folded into the packed Wq / q bias (sodt_wmsa_pack): q^T leaves the MFMAs scaled and S^T ready for
-      // exp2; the q saved for the backward is the reference's unscaled one
+      // hd^-1/2 x log2 e is folded into the packed Wq / q bias (sodt_wmsa_pack): q^T leaves the MFMAs scaled and S^T ready for exp2
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms) {
-        if (SAVE) pq[ms] = pk16<T>(qT[ms] * (1.0f / scale2));
         pqs[ms] = pk16<T>(qT[ms]);
         pkk[ms] = pk16<T>(kT[ms]); pv[ms] = pk16<T>(vv[ms]);
       }
@@ -310,30 +306,7 @@ __global__ __launch_bounds__(512, 2) void wmsa_hg_kernel(const WArgs a) {
       __syncthreads();                                   // B2/4/6: everyone is done with the weight buffer (step 2: and the LN1 tile)
       HG_STAMP(3);
       dma_part(step + 1, 0, 3);                          // next heads' weights / Wproj land under the softmax (pieces 3..8: inside it)
-      if (SAVE && valid) {
-        unsigned char* qb = a.qkvw + (size_t)(whoff + h) * (3 * 64 * WHD * E);     // uniform
-        const unsigned lo = (unsigned)(t * (WHD * E) + g * 8);
-#pragma unroll
-        for (int ms = 0; ms < 4; ++ms) {
-          *(k16_t*)(qb + (lo + (unsigned)(16 * ms * WHD * E))) = pq[ms];
-          *(k16_t*)(qb + (lo + (unsigned)(64 * WHD * E + 16 * ms * WHD * E))) = pkk[ms];
-        }
-        // v -> [token][16] through a 1 KB per-wave patch, two token strips at a time (the accumulator holds four tokens of
-        // ONE channel per lane)
-        lds_u8* const vp = sm3 + HG_VP_OFF + w * 1024;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          wave_sync();
-#pragma unroll
-          for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              *(__attribute__((address_space(3))) T*)(vp + ((16 * m2 + 4 * g + r) * WHD + t) * E) = from_f<T>(vv[2 * half + m2][r]);
-          wave_sync();
-          *(uint4*)(qb + (unsigned)(2 * 64 * WHD * E + half * 1024 + lane * 16)) =
-              u4((u32x4_)*(const __attribute__((address_space(3))) u32x4_*)(vp + lane * 16));
-        }
-      }
+      // (training: nothing of q / k / v is saved - the backward, sodt_wmsa_block_bwd, recomputes them from xn1)
 
       HG_STAMP(4);
       // Softmax of S^T (already in log2 units: bias x log2 e is the accumulator's initial value).  FAST form: no row maximum -

@@ -662,9 +662,11 @@ class Engine:
         wpk = P["wmsa"].get(pre) if (ws == 8 and H % 8 == 0 and W % 8 == 0) else None
         fused = wpk is not None
         if fused:
-            # LN1 + QKV + window attention + proj + residual + LN2 in ONE launch (csrc/wmsa_block.hip); training also writes the
-            # tensors the backward needs: q/k/v and the log-sum-exp in window-major order (sodt_window_attn_bwd_wm)
-            qkvw = plan.buf(tag + ".qkvw", (M // 64, HEADS, 3, 64, Cc // HEADS))
+            # LN1 + QKV + window attention + proj + residual + LN2 in ONE launch (csrc/wmsa_hg.hip / wmsa_block.hip); training also
+            # writes what the backward needs: xn1, the attention output, the LayerNorm statistics and the window-major
+            # log-sum-exp.  q / k / v are saved by the f32 parity kernel only (sodt_window_attn_bwd_wm reads them back); the bf16
+            # backward recomputes them from xn1 and the parameter pack (sodt_wmsa_block_bwd): 604 MB less written per launch
+            qkvw = plan.buf(tag + ".qkvw", (M // 64, HEADS, 3, 64, Cc // HEADS)) if (plan.training and plan.dt == torch.float32) else None
             lsew = plan.buf(tag + ".lsew", (M // 64, HEADS, 64), torch.float32)
             if plan.training:
                 ops.wmsa_block_fwd(x_in, wpk, xm, xn2, st1, st2, xn1, qkvw, lsew, ao, B, H, W, Cc, HEADS, ws, shift)
@@ -697,7 +699,7 @@ class Engine:
             ops.gemm_nt(segs, w[pre + "mlp.conv1.weight"], cp, M, Cc, 4 * Cc, spatial=(H, W), bias=p[pre + "mlp.conv1.bias"],
                         gelu_out=ca)
             ops.gemm_nt([SegSpec(ca)], w[pre + "mlp.fc2.weight"], xo, M, Cc, Cc, bias=p[pre + "mlp.fc2.bias"], resid=xm)
-        plan.saved[tag] = dict(x_in=x_in, geo=(B, H, W, Cc, ws, shift), fused=fused)
+        plan.saved[tag] = dict(x_in=x_in, geo=(B, H, W, Cc, ws, shift), fused=fused, wpk=wpk)
         return xo
 
     def _block_bwd(self, plan, P, tag, blk, dY, dX):
@@ -744,7 +746,10 @@ class Engine:
         dqkv = plan.buf(f"g.dqkv.{Cc}", (M, 3 * Cc))
         L2 = 2 * ws - 1
         dbt = plan.buf(f"g.dbt.{L2}", (HEADS, L2 * L2), torch.float32, zero=True)
-        if sv["fused"]:
+        if sv["fused"] and plan.dt == torch.bfloat16:
+            ops.wmsa_block_bwd(xn1, sv["wpk"], P["bias_t"][pre + "attn.relative_position_bias_table"], dao, b[tag + ".lsew"],
+                               dqkv, dbt, B, H, W, Cc, HEADS, ws, shift)
+        elif sv["fused"]:
             ops.window_attn_bwd_wm(b[tag + ".qkvw"], P["bias_t"][pre + "attn.relative_position_bias_table"], dao, b[tag + ".lsew"],
                                    dqkv, dbt, B, H, W, Cc, HEADS, ws, shift)
         else:

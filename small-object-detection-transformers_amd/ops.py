@@ -276,6 +276,12 @@ def window_attn_bwd_wm(qkvw, bias_t, dout, lsew, dqkv, dbias_t, B, H, W, Cc, hea
             B, H, W, Cc, heads, ws, shift, dt_code(dout))
 
 
+def wmsa_block_bwd(xn1, wpk, bias_t, dout, lsew, dqkv, dbias_t, B, H, W, Cc, heads, ws, shift):
+    """Attention backward of the fused block (bf16) with q / k / v recomputed from the saved LN1 output and the parameter pack."""
+    _launch("sodt_wmsa_block_bwd", _p(xn1), _p(wpk), _p(bias_t), _p(dout), _p(lsew), _p(dqkv), _p(dbias_t),
+            B, H, W, Cc, heads, ws, shift, dt_code(dout))
+
+
 def frontend_fwd(rgb, ir_plane, ir_bstride, w, b, gamma, beta, out, B, S, ca_ws=1):
     _launch("sodt_frontend_fwd", _p(rgb), _p(ir_plane), ir_bstride, _p(w), _p(b), _p(gamma), _p(beta), _p(out),
             B, S, ca_ws, dt_code(out))

@@ -21,11 +21,11 @@ wpk = torch.zeros(ops.wmsa_pack_bytes(C, HEADS, WS, L.BF16) // 2, device=dev, dt
 ops.wmsa_pack(qw, qb, pw, pb, tab, n1w, n1b, n2w, n2b, wpk, C, HEADS, WS)
 xm, xn2, xn1, ao = (torch.empty(M, C, device=dev, dtype=dt) for _ in range(4))
 st1, st2 = torch.empty(M, 2, device=dev), torch.empty(M, 2, device=dev)
-qkvw = torch.empty(M // 64, HEADS, 3, 64, 16, device=dev, dtype=dt); lsew = torch.empty(M // 64, HEADS, 64, device=dev)
+lsew = torch.empty(M // 64, HEADS, 64, device=dev)
 torch.cuda.synchronize()
 shift = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 ops.wmsa_block_fwd(x, wpk, xm, xn2, None, None, None, None, None, None, B, H, H, C, HEADS, WS, shift)
 torch.cuda.synchronize()
-ops.wmsa_block_fwd(x, wpk, xm, xn2, st1, st2, xn1, qkvw, lsew, ao, B, H, H, C, HEADS, WS, shift)
+ops.wmsa_block_fwd(x, wpk, xm, xn2, st1, st2, xn1, None, lsew, ao, B, H, H, C, HEADS, WS, shift)
 torch.cuda.synchronize()
 print("done", flush=True)

@@ -53,7 +53,13 @@ def cost(name, args):
     if name == "sodt_wmsa_block_fwd":
         B, H, W, C = (val(args[i]) for i in (10, 11, 12, 13))
         T = B * H * W
-        return (f"T={T} C={C} train", T * (8 * C * ES + 12 * 4 + 16), 8.0 * T * C * C + 4.0 * T * 64 * C)
+        nrow = 8 if args[7] else 5       # x in; x_mid, xn2, xn1, ao out (+ q, k, v: the f32 parity kernel only)
+        return (f"T={T} C={C} train", T * (nrow * C * ES + 12 * 4 + 16), 8.0 * T * C * C + 4.0 * T * 64 * C)
+    if name == "sodt_wmsa_block_bwd":
+        B, H, W, C = (val(args[i]) for i in (7, 8, 9, 10))
+        T = B * H * W
+        # xn1, dout in; dqkv (3 rows) out; + the 6 T C^2 flops of the recomputed QKV product on top of the five attention products
+        return (f"T={T} C={C} ws=8 bwd+qkv recompute", T * (5 * C * ES + 12 * 4), 10.0 * T * 64 * C + 6.0 * T * C * C)
     if name in ("sodt_window_attn_fwd", "sodt_window_attn_bwd", "sodt_window_attn_bwd_wm"):
         o = {"sodt_window_attn_fwd": 4, "sodt_window_attn_bwd": 8, "sodt_window_attn_bwd_wm": 6}[name]
         B, H, W, C, heads, ws = (val(args[o + i]) for i in range(6))
