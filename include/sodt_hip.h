@@ -70,6 +70,11 @@ typedef struct {
                                   * pre-activation h = A1 W1^T (+ bias), the second K/2 give dh_act = A2 W2^T;
                                   * C = dh_act * gelu'(h).  Backward of Linear-GELU-Linear without saving h
                                   * (backbone_vit.py:886-904): A = [xn | dy], W = [fc1.weight | fc2.weight^T] */     /* C is float regardless of dtype */
+#define SODT_EPI_LNBWD 1024      /* the GEMM's result dy = A W^T is the gradient of a LayerNorm's OUTPUT and never stored: C = [R +]
+                                  * LN'(dy) with x = aux [M][ldaux], (mean, rstd) = scale (f32 [M][2]), gamma = shift (f32 [N]);
+                                  * ln_dgamma / ln_dbeta (f32 [N]) += the parameter gradients.  bf16 pipelined kernel only, N == 192 (a token row in one
+                                  * workgroup), one plain K-segment; optional SODT_EPI_RESID (the residual path's gradient).
+                                  * backbone_vit.py:1089,1128 (norm1 / norm2 of SwinTransformerBlock) */
 
 typedef struct {
   sodt_aspec a;                 /* A [M][K] as K-segments */
@@ -84,6 +89,7 @@ typedef struct {
   int M, N, K, flags;
   int oscatter, omul, ody, odx, OH, OW;   /* optional output-row scatter (PatchMerging backward) */
   int det_na, det_no, det_hw;
+  float* ln_dgamma; float* ln_dbeta;      /* SODT_EPI_LNBWD: f32 [N] each, += (atomics) */
 } sodt_gemm_args;
 
 /* C = epilogue(A @ W^T): every nn.Linear / 1x1 / 2x2 / 3x3 Conv2d forward and every

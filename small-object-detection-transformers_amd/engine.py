@@ -168,6 +168,10 @@ class Engine:
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
         self.ddp = None     # set by ddp.attach()
         self.use_fused_wmsa = True     # tests / tools may switch the fused block kernel off to compare with the four launches it replaces
+        # LayerNorm backward as the epilogue of the GEMM that produces its input gradient (SODT_EPI_LNBWD): built and pinned
+        # (tests/test_kernels_gpu.py), but measured SLOWER than the two launches it replaces at the bench shapes (0.45 vs 0.34 ms
+        # at K = 576: profiles/r04_lnfold_ab.md), so the step does not use it
+        self.use_ln_fold = False
         # 64 MiB of f32 for the per-slice partial tiles of the bf16 weight-gradient GEMMs (largest need: 12.5 M floats)
         self._tn_scratch = torch.empty(16 << 20, dtype=torch.float32, device=self.dev)
         ops.set_tn_scratch(self._tn_scratch)
@@ -724,7 +728,7 @@ class Engine:
                 ops.gemm_nt([SegSpec(xn2), SegSpec(dY)], P["wcat"][pre + "mlp.fc1.weight"], dh, M, 4 * Cc, 2 * Cc,
                             bias=p[pre + "mlp.fc1.bias"], dgelu_rc=True)
             ops.gemm_tn(dh, [SegSpec(xn2)], g[pre + "mlp.fc1.weight"], M, 4 * Cc, Cc, dbias=g[pre + "mlp.fc1.bias"])
-            ops.gemm_nt([SegSpec(dh)], wT[pre + "mlp.fc1.weight"], dxn, M, Cc, 4 * Cc)
+            dln2 = (dh, 4 * Cc)
         else:
             u, cp, ca = b[tag + ".u"], b[tag + ".cp"], b[tag + ".ca"]
             dc = plan.buf(f"g.dc.{Cc}", (M, Cc))
@@ -737,8 +741,15 @@ class Engine:
             segs = [SegSpec(dc, Cc, 0, -dy, -dx, 1, 0, H, W) for (dy, dx) in TAPS2]
             ops.gemm_nt(segs, wT[pre + "mlp.conv1.weight"], du, M, Cc, 4 * Cc, spatial=(H, W))
             ops.gemm_tn(du, [SegSpec(xn2)], g[pre + "mlp.fc1.weight"], M, Cc, Cc, dbias=g[pre + "mlp.fc1.bias"])
-            ops.gemm_nt([SegSpec(du)], wT[pre + "mlp.fc1.weight"], dxn, M, Cc, Cc)
-        ops.layernorm_bwd(dxn, xm, b[tag + ".st2"], p[pre + "norm2.weight"], dY, dxm, g[pre + "norm2.weight"], g[pre + "norm2.bias"], M, Cc)
+            dln2 = (du, Cc)
+        # d(xn2) = dln2 @ fc1.weight and the LayerNorm-2 backward (+ the residual path's dY): ONE launch where a token row fits a
+        # 192-column tile (stage 1, bf16: SODT_EPI_LNBWD - d(xn2) never goes to HBM), otherwise the GEMM and sodt_layernorm_bwd
+        if self.use_ln_fold and ops.ln_bwd_fold_ok(M, Cc, dln2[1], plan.dt):
+            ops.gemm_nt([SegSpec(dln2[0])], wT[pre + "mlp.fc1.weight"], dxm, M, Cc, dln2[1], resid=dY,
+                        ln_bwd=(xm, b[tag + ".st2"], p[pre + "norm2.weight"], g[pre + "norm2.weight"], g[pre + "norm2.bias"]))
+        else:
+            ops.gemm_nt([SegSpec(dln2[0])], wT[pre + "mlp.fc1.weight"], dxn, M, Cc, dln2[1])
+            ops.layernorm_bwd(dxn, xm, b[tag + ".st2"], p[pre + "norm2.weight"], dY, dxm, g[pre + "norm2.weight"], g[pre + "norm2.bias"], M, Cc)
         # attention
         ops.gemm_tn(dxm, [SegSpec(ao)], g[pre + "attn.proj.weight"], M, Cc, Cc, dbias=g[pre + "attn.proj.bias"])
         dao = dxn
@@ -758,8 +769,12 @@ class Engine:
                                 dbt, scratch, B, H, W, Cc, HEADS, ws, shift)
         ops.transpose_f32(dbt, g[pre + "attn.relative_position_bias_table"], HEADS, L2 * L2, accumulate=2)
         ops.gemm_tn(dqkv, [SegSpec(xn1)], g[pre + "attn.qkv.weight"], M, 3 * Cc, Cc, dbias=g[pre + "attn.qkv.bias"])
-        ops.gemm_nt([SegSpec(dqkv)], wT[pre + "attn.qkv.weight"], dxn, M, Cc, 3 * Cc)
-        ops.layernorm_bwd(dxn, x_in, b[tag + ".st1"], p[pre + "norm1.weight"], dxm, dX, g[pre + "norm1.weight"], g[pre + "norm1.bias"], M, Cc)
+        if self.use_ln_fold and ops.ln_bwd_fold_ok(M, Cc, 3 * Cc, plan.dt):        # d(xn1) = dqkv @ qkv.weight + LayerNorm-1 backward + dxm, one launch
+            ops.gemm_nt([SegSpec(dqkv)], wT[pre + "attn.qkv.weight"], dX, M, Cc, 3 * Cc, resid=dxm,
+                        ln_bwd=(x_in, b[tag + ".st1"], p[pre + "norm1.weight"], g[pre + "norm1.weight"], g[pre + "norm1.bias"]))
+        else:
+            ops.gemm_nt([SegSpec(dqkv)], wT[pre + "attn.qkv.weight"], dxn, M, Cc, 3 * Cc)
+            ops.layernorm_bwd(dxn, x_in, b[tag + ".st1"], p[pre + "norm1.weight"], dxm, dX, g[pre + "norm1.weight"], g[pre + "norm1.bias"], M, Cc)
 
     # ------------------------------------------------------------------ PatchMerging
     def _merge_fwd(self, plan, P, tag, x, B, H, W, Cc):
