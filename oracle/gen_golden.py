@@ -466,6 +466,54 @@ def spp_head_goldens(ref_model, out):
     print("[pin] wrote spp_head_512.pt")
 
 
+def sr_goldens(out):
+    """The super-resolution auxiliary branch from the reference's OWN classes (basics/models/sr_decoder_noBN_noD.py:6-45,
+    edsr.py:55-102, deeplabedsr.py:35-73; importable although Model(sr=True) itself cannot reach them, SURVEY.md section 8
+    config reality row 5): Decoder(c1 16, c2 32), EDSR(4, 64, factor 8, depth 2) and the full DeepLab(4, 128, 512, factor 2) -
+    EDSR depth 16, 2.9 M parameters - on small maps.  Weights are the PROCEDURAL ones of ref_torch.procedural_from_shapes
+    (re-creatable anywhere from names and shapes), so only inputs, outputs, input gradients, gradient norms and 64 strided
+    gradient values per parameter are stored.  Each case pins the oracle restatement (0.0 difference)."""
+    dec_m = importlib.import_module("reference.basics.models.sr_decoder_noBN_noD")
+    edsr_m = importlib.import_module("reference.basics.models.edsr")
+    dl_m = importlib.import_module("reference.basics.models.deeplabedsr")
+    gold = {}
+
+    def case(name, m, pfx, inputs, run_ref, run_oracle):
+        shapes = {pfx + k: tuple(v.shape) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+        psd = R.procedural_from_shapes(shapes)
+        with torch.no_grad():
+            load_into(m, psd, prefix=pfx)
+        ins = [t.clone().requires_grad_(True) for t in inputs]
+        y = run_ref(m, *ins)
+        gsel = R._hash01("sr:" + name, y.numel()).view(y.shape).float()
+        (y * gsel).sum().backward()
+        osd = {k: v.clone().requires_grad_(True) for k, v in psd.items()}
+        ins2 = [t.clone().requires_grad_(True) for t in inputs]
+        yo = run_oracle(osd, *ins2)
+        (yo * gsel).sum().backward()
+        gn = {pfx + k: float(p.grad.double().norm()) for k, p in m.named_parameters()}
+        gd = max(abs(float(osd[k].grad.double().norm()) - v) / (v + 1e-9) for k, v in gn.items())
+        di = max(maxdiff(a.grad, b.grad) for a, b in zip(ins, ins2))
+        print(f"[pin] SR {name}: out {tuple(y.shape)} diff {maxdiff(y, yo):.2e} (|y| max {float(y.abs().max()):.2f}), input grads {di:.2e}, "
+              f"grad norms (rel) {gd:.2e}; {sum(p.numel() for p in m.parameters())} parameters")
+        assert maxdiff(y, yo) <= 1e-4 * max(1.0, float(y.abs().max())) and gd <= 1e-4
+        gsub = {pfx + k: p.grad.detach().reshape(-1)[::max(1, p.numel() // 64)][:64].clone() for k, p in m.named_parameters()}
+        step = 4 if y.shape[-1] > 64 else 1
+        gold[name] = dict(shapes=shapes, inputs=[t.detach().clone() for t in inputs], y_sub=y.detach()[..., ::step, ::step].contiguous().clone(),
+                          y_step=step, y_absmax=float(y.abs().max()), dinputs=[t.grad.clone() for t in ins], gnorm=gn, gsub=gsub)
+
+    h = lambda tag, *shape: (R._hash01("srin:" + tag, int(torch.tensor(shape).prod())).view(*shape).float() * 2)
+    case("decoder", dec_m.Decoder(16, 32), "sr_decoder.", [h("dl", 2, 16, 12, 10), h("dx", 2, 32, 6, 5)],
+         lambda m, low, x: m(x, low, 2), lambda sd, low, x: R.sr_decoder(sd, "sr_decoder.", x, low, 2))
+    case("edsr", edsr_m.EDSR(num_channels=4, input_channel=64, factor=8, depth=2), "edsr.", [h("ex", 1, 64, 7, 6)],
+         lambda m, x: m(x), lambda sd, x: R.edsr(sd, "edsr.", x))
+    # as Model would build it (model.py:113-115 with c1 = 128, c2 = 512): low-level feature 128 @ t, x 512 @ t / 2
+    case("deeplab", dl_m.DeepLab(4, 128, 512, factor=2), "model_up.", [h("low", 1, 128, 16, 16), h("x", 1, 512, 8, 8)],
+         lambda m, low, x: m(low, x), lambda sd, low, x: R.deeplab_sr(sd, "model_up.", low, x, 2))
+    torch.save(gold, os.path.join(out, "sr.pt"))
+    print("[pin] wrote sr.pt")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -474,6 +522,7 @@ def main():
     ap.add_argument("--only-autocast", action="store_true")
     ap.add_argument("--only-spp", action="store_true")
     ap.add_argument("--only-spp-head", action="store_true")
+    ap.add_argument("--only-sr", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
@@ -490,12 +539,16 @@ def main():
     if a.only_spp_head:
         spp_head_goldens(ref_model, GOLD)
         return
+    if a.only_sr:
+        sr_goldens(GOLD)
+        return
     loss_goldens(GOLD)
     nms_goldens(GOLD)
     if a.only_nms:
         return
     per_module_goldens(ref_vit, ref_common, GOLD)
     spp_goldens(ref_common, GOLD)
+    sr_goldens(GOLD)
     if not a.skip_full:
         full_model_goldens(ref_model, GOLD)
         autocast_goldens(ref_model, GOLD)

@@ -420,6 +420,49 @@ def model_forward(sd: SD, x_rgb: Tensor, x_ir: Tensor, training: bool = True,
 
 
 # ----------------------------------------------------------------------------
+# super-resolution auxiliary branch (DeepLab = Decoder + EDSR x8), used in training with --super
+# ----------------------------------------------------------------------------
+def sr_decoder(sd: SD, pfx: str, x: Tensor, low: Tensor, factor: int = 2) -> Tensor:
+    """Decoder.forward (basics/models/sr_decoder_noBN_noD.py:27-45): 1x1 convs (no bias) + ReLU on both inputs, bilinear
+    (align_corners=True) resize of both to low's size x (factor // 2), concat (x first), 3x3 - ReLU - 3x3 - ReLU - 1x1(+bias)."""
+    lo = F.relu(F.conv2d(low, sd[pfx + "conv1.weight"]))
+    xx = F.relu(F.conv2d(x, sd[pfx + "conv2.weight"]))
+    size = [d * (factor // 2) for d in lo.shape[2:]]
+    xx = F.interpolate(xx, size=size, mode="bilinear", align_corners=True)
+    if factor > 1:
+        lo = F.interpolate(lo, size=size, mode="bilinear", align_corners=True)
+    z = torch.cat((xx, lo), 1)
+    z = F.relu(F.conv2d(z, sd[pfx + "last_conv.0.weight"], None, padding=1))
+    z = F.relu(F.conv2d(z, sd[pfx + "last_conv.2.weight"], None, padding=1))
+    return F.conv2d(z, sd[pfx + "last_conv.4.weight"], sd[pfx + "last_conv.4.bias"])
+
+
+def edsr(sd: SD, pfx: str, x: Tensor) -> Tensor:
+    """EDSR.forward (basics/models/edsr.py:55-102): head 3x3; ResBlocks (3x3 - ReLU - 3x3, + input; res_scale 1) and a closing 3x3,
+    + head output; tail: log2(scale) x (3x3 to 4 n_feat channels + PixelShuffle(2)), 3x3 to num_channels.  Depth / scale are read
+    off the state dict (body.<i>.body.0 / tail.0.<2j>)."""
+    def conv(name, t):
+        return F.conv2d(t, sd[pfx + name + ".weight"], sd[pfx + name + ".bias"], padding=1)
+    h = conv("head.0", x)
+    r = h
+    i = 0
+    while f"{pfx}body.{i}.body.0.weight" in sd:
+        r = r + conv(f"body.{i}.body.2", F.relu(conv(f"body.{i}.body.0", r)))
+        i += 1
+    r = conv(f"body.{i}", r) + h
+    j = 0
+    while f"{pfx}tail.0.{j}.weight" in sd:
+        r = F.pixel_shuffle(conv(f"tail.0.{j}", r), 2)
+        j += 2
+    return conv("tail.1", r)
+
+
+def deeplab_sr(sd: SD, pfx: str, low: Tensor, x: Tensor, factor: int = 2) -> Tensor:
+    """DeepLab.forward (basics/models/deeplabedsr.py:61-73): EDSR(sr_decoder(x, low_level_feat, factor))."""
+    return edsr(sd, pfx + "edsr.", sr_decoder(sd, pfx + "sr_decoder.", x, low, factor))
+
+
+# ----------------------------------------------------------------------------
 # NMS spec (greedy; torchvision.ops.nms semantics: suppress IoU > thr)
 # basics/utils/general.py:425-512 with merge=False path as the pinned spec
 # ----------------------------------------------------------------------------

@@ -152,3 +152,29 @@ def test_spp_matches_reference_golden():
     assert float((y - g["y"]).abs().max()) < 1e-5 and float((x.grad - g["dx"]).abs().max()) < 1e-5
     for k, v in g["stats_after"].items():
         assert float((ns[k] - v).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["decoder", "edsr", "deeplab"])
+def test_sr_branch_matches_reference_golden(name):
+    """oracle sr_decoder / edsr / deeplab_sr against the reference's own Decoder / EDSR / DeepLab classes (tests/golden/sr.pt,
+    oracle/gen_golden.py --only-sr; sr_decoder_noBN_noD.py:6-45, edsr.py:55-102, deeplabedsr.py:35-73): output, input
+    gradients, every parameter's gradient norm and 64 strided gradient values, on the procedural weights."""
+    g = torch.load(os.path.join(GOLD, "sr.pt"))[name]
+    sd = {k: v.requires_grad_(True) for k, v in R.procedural_from_shapes(g["shapes"]).items()}
+    ins = [t.clone().requires_grad_(True) for t in g["inputs"]]
+    if name == "decoder":
+        y = R.sr_decoder(sd, "sr_decoder.", ins[1], ins[0], 2)
+    elif name == "edsr":
+        y = R.edsr(sd, "edsr.", ins[0])
+    else:
+        y = R.deeplab_sr(sd, "model_up.", ins[0], ins[1], 2)
+    gsel = R._hash01("sr:" + name, y.numel()).view(y.shape).float()
+    (y * gsel).sum().backward()
+    st = g["y_step"]
+    assert float((y.detach()[..., ::st, ::st] - g["y_sub"]).abs().max()) <= 1e-4 * max(1.0, g["y_absmax"])
+    for a, b in zip(ins, g["dinputs"]):
+        assert float((a.grad - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    for k, v in g["gnorm"].items():
+        assert abs(float(sd[k].grad.double().norm()) - v) <= 1e-4 * (v + 1e-9), k
+        got = sd[k].grad.reshape(-1)[::max(1, sd[k].numel() // 64)][:64]
+        assert float((got - g["gsub"][k]).abs().max()) <= 1e-4 * (float(g["gsub"][k].abs().max()) + 1e-6), k
