@@ -70,6 +70,9 @@ typedef struct {
                                   * pre-activation h = A1 W1^T (+ bias), the second K/2 give dh_act = A2 W2^T;
                                   * C = dh_act * gelu'(h).  Backward of Linear-GELU-Linear without saving h
                                   * (backbone_vit.py:886-904): A = [xn | dy], W = [fc1.weight | fc2.weight^T] */     /* C is float regardless of dtype */
+#define SODT_EPI_RELU 2048       /* v = max(v, 0) after the bias: the ReLUs of the super-resolution branch (sr_decoder_noBN_noD.py:30-38,
+                                  * edsr.py:44) */
+#define SODT_EPI_DRELU 4096      /* v = aux[m][n] > 0 ? v : 0 - the gradient through a ReLU whose OUTPUT is aux (applied before RESID) */
 #define SODT_EPI_LNBWD 1024      /* the GEMM's result dy = A W^T is the gradient of a LayerNorm's OUTPUT and never stored: C = [R +]
                                   * LN'(dy) with x = aux [M][ldaux], (mean, rstd) = scale (f32 [M][2]), gamma = shift (f32 [N]);
                                   * ln_dgamma / ln_dbeta (f32 [N]) += the parameter gradients.  bf16 pipelined kernel only, N == 192 (a token row in one
@@ -141,6 +144,24 @@ int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const void* out, 
                          const float* lse, void* dqkv, float* dbias_t, float* dq_acc,
                          int B, int H, int W, int C, int heads, int ws, int shift,
                          int dtype, sodt_stream_t st);
+
+/* ---- super-resolution auxiliary branch (deeplabedsr.py:35-73): data movement between its convolutions, token-major [B][H][W][C] ----
+ * sodt_bilinear_up2_fwd/bwd: F.interpolate(x, size = (2H, 2W), mode = 'bilinear', align_corners = True) (sr_decoder_noBN_noD.py:37) and
+ *   its adjoint (dx = sum over the output pixels a source pixel contributes to; written, not accumulated).  y / dy may be a
+ *   column slice of a wider buffer (row stride ldy / lddy elements, pointer already at the slice); relu_out != NULL: x was the
+ *   output of a ReLU ([B*H*W][C]) and dx is zeroed where it was not positive.
+ * sodt_pixel_shuffle2: nn.PixelShuffle(2) (edsr.py:23): out[b][2y+i][2x+j][c] = in[b][y][x][4c + 2i + j], in [B][H][W][4C] ->
+ *   out [B][2H][2W][C]; inverse != 0 runs the adjoint (= inverse permutation) out -> in.
+ * sodt_add_rows: dst[m][dcol .. dcol + C) += src[m][scol .. scol + C) (gradient accumulation where a feature has two consumers).
+ * sodt_nchw_f32_from_rows / sodt_rows_from_nchw_f32: y (B, C, H, W) f32 <-> token-major rows [B*H*W][ld] run dtype (C <= ld, the
+ *   pad columns are written as zeros): the branch's output / its incoming gradient at the model boundary. */
+int sodt_bilinear_up2_fwd(const void* x, void* y, int ldy, int B, int H, int W, int C, int dtype, sodt_stream_t st);
+int sodt_bilinear_up2_bwd(const void* dy, int lddy, void* dx, const void* relu_out, int B, int H, int W, int C, int dtype,
+                          sodt_stream_t st);
+int sodt_pixel_shuffle2(const void* in, void* out, int B, int H, int W, int C, int inverse, int dtype, sodt_stream_t st);
+int sodt_add_rows(void* dst, int ldd, int dcol, const void* src, int lds, int scol, long M, int C, int dtype, sodt_stream_t st);
+int sodt_nchw_f32_from_rows(const void* rows, int ld, float* y, int B, int C, int H, int W, int dtype, sodt_stream_t st);
+int sodt_rows_from_nchw_f32(const float* y, void* rows, int ld, int B, int C, int H, int W, int dtype, sodt_stream_t st);
 
 /* ---- fused W-MSA / SW-MSA half of a Swin block (csrc/wmsa_block.hip) -------------------------------------------
  * x_mid = x + Proj(WindowAttention(LN1(x))) and xn2 = LN2(x_mid) in ONE launch: SwinTransformerBlock.forward
@@ -287,7 +308,7 @@ typedef struct {
   int d0, d1, d2;       /* source viewed as [d0][d1][d2] */
   int p0, p1, p2;       /* destination dims order: dst[i_p0][i_p1][i_p2] */
   int dst_ld;           /* elements per destination "row" (>= product of the trailing two dims) */
-  int pad_;
+  int inner_ld;         /* elements between consecutive i_p1 (0: the extent of dims[p2], i.e. dense) - > extent when dims[p2] is zero-padded */
 } sodt_prep_desc;
 int sodt_prep_weights(const sodt_prep_desc* table_dev, int n, int max_elems, int dtype, sodt_stream_t st);
 

@@ -26,7 +26,7 @@ MAX_SEG = 9
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_RESID, EPI_GELU_DUAL, EPI_DGELU = 1, 2, 4, 8
 EPI_STATS, EPI_AFFINE_SILU, EPI_DETECT, EPI_OUT_F32 = 16, 32, 64, 128
-EPI_GELU, EPI_DGELU_RC, EPI_LNBWD = 256, 512, 1024
+EPI_GELU, EPI_DGELU_RC, EPI_LNBWD, EPI_RELU, EPI_DRELU = 256, 512, 1024, 2048, 4096
 STATS_REPL = 16      # SODT_STATS_REPL: replicas of the [2][N] f64 BatchNorm statistics buffer
 
 
@@ -70,7 +70,7 @@ class PrepDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p),
                 ("d0", C.c_int), ("d1", C.c_int), ("d2", C.c_int),
                 ("p0", C.c_int), ("p1", C.c_int), ("p2", C.c_int),
-                ("dst_ld", C.c_int), ("pad_", C.c_int)]
+                ("dst_ld", C.c_int), ("inner_ld", C.c_int)]
 
 
 # name -> argtypes (all return int except sodt_version)
@@ -117,6 +117,12 @@ SIGNATURES = {
     "sodt_sgd_ema_step": [_P, _P, _P, _P, _P, _I, _P, _L, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                           _I, _F, _F, _P],
     "sodt_preprocess_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sodt_bilinear_up2_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sodt_bilinear_up2_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sodt_pixel_shuffle2": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sodt_add_rows": [_P, _I, _I, _P, _I, _I, _L, _I, _I, _P],
+    "sodt_nchw_f32_from_rows": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "sodt_rows_from_nchw_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sodt_debug_wmsa_stamps": [_P, _I],
     "sodt_debug_wmsa_hg_stamps": [_P, _I],
 }

@@ -1037,6 +1037,7 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
   if ((g->flags & SODT_EPI_BIAS) && (!g->bias || (((uintptr_t)g->bias) & 15))) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_RESID) && (!g->R || (g->ldr % kpl))) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_DGELU) && (!g->aux || (g->ldaux % kpl))) return SODT_EINVAL;
+  if ((g->flags & SODT_EPI_DRELU) && (!g->aux || (g->ldaux % kpl) || (((uintptr_t)g->aux) & 15) || (g->flags & SODT_EPI_DGELU))) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_GELU_DUAL) && (!g->C2 || (g->ldc2 % kpl))) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_STATS) && !g->stats) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_AFFINE_SILU) && (!g->scale || !g->shift || ((((uintptr_t)g->scale) | ((uintptr_t)g->shift)) & 15))) return SODT_EINVAL;
@@ -1056,7 +1057,9 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
     if (!(g->flags & SODT_EPI_DETECT) && (KB % 128) == 0 && KB <= 384 && seg_ok && !g_force_tiled) {
       hipStream_t s_ = (hipStream_t)st;
       const int kplv = dtype == SODT_BF16 ? 8 : 4;
-      const bool bs_ok = (g->N % kplv) == 0 && (g->flags & SODT_EPI_OUT_F32) == 0 && g_variant != 2;
+      // (that kernel adds the residual before the generic epilogue: a ReLU / ReLU mask must come first, so not with both)
+      const bool relu_resid = (g->flags & (SODT_EPI_RELU | SODT_EPI_DRELU)) && (g->flags & SODT_EPI_RESID);
+      const bool bs_ok = (g->N % kplv) == 0 && (g->flags & SODT_EPI_OUT_F32) == 0 && g_variant != 2 && !relu_resid;
       if (bs_ok) {
         const bool stt = (g->flags & SODT_EPI_STATS) != 0;
         const bool simple = g->a.nseg == 1 && !g->a.spatial && !g->oscatter;

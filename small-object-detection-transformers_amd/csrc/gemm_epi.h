@@ -43,6 +43,10 @@ __device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int rtf
 #pragma unroll
     for (int j = 0; j < KPL; ++j) v[j] = gelu_t<T>(v[j]);
   }
+  if (flags & SODT_EPI_RELU) {
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) v[j] = fmaxf(v[j], 0.f);
+  }
   if (flags & SODT_EPI_AFFINE_SILU) {
     float sc[KPL], sh[KPL];
     if (full) {
@@ -69,6 +73,14 @@ __device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int rtf
     else { for (int j = 0; j < KPL; ++j) x[j] = (n + j < g.N) ? to_f(ap[j]) : 0.f; }
 #pragma unroll
     for (int j = 0; j < KPL; ++j) v[j] *= dgelu_t<T>(x[j]);
+  }
+  if (flags & SODT_EPI_DRELU) {            // gradient through a ReLU whose OUTPUT is aux: passes where the output was positive
+    float x[KPL];
+    const T* ap = (const T*)g.aux + m * g.ldaux + n;
+    if (full) { unpack<T>(*(const uint4*)ap, x); }
+    else { for (int j = 0; j < KPL; ++j) x[j] = (n + j < g.N) ? to_f(ap[j]) : 0.f; }
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) v[j] = x[j] > 0.f ? v[j] : 0.f;
   }
   if (flags & SODT_EPI_RESID) {
     const long rr = g.rmod > 0 ? (m % g.rmod) : m;

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const sodt_prep_desc* __restr
     const int i2 = (int)(i % e2); const long r = i / e2;
     const int i1 = (int)(r % e1); const int i0 = (int)(r / e1);
     const long s = (long)i0 * sstr[d.p0] + (long)i1 * sstr[d.p1] + (long)i2 * sstr[d.p2];
-    dst[(long)i0 * d.dst_ld + (long)i1 * e2 + i2] = from_f<T>(d.src[s]);
+    dst[(long)i0 * d.dst_ld + (long)i1 * (d.inner_ld > 0 ? d.inner_ld : e2) + i2] = from_f<T>(d.src[s]);
   }
 }
 

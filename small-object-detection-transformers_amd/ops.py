@@ -132,7 +132,7 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
             stats: Optional[torch.Tensor] = None, affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
             out_f32: bool = False, detect: Optional[Tuple[int, int, int]] = None,
             oscatter: Optional[Tuple[int, int, int, int, int]] = None, w_off: int = 0,
-            gelu_only: bool = False, dgelu_rc: bool = False,
+            gelu_only: bool = False, dgelu_rc: bool = False, relu: bool = False, drelu_aux: Optional[torch.Tensor] = None, aux_off: int = 0,
             ln_bwd: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> None:
     """out[M][N] = epilogue(concat_k(segs) @ W[N][K]^T); see SODT_EPI_* in include/sodt_hip.h."""
     g = L.GemmArgs()
@@ -178,6 +178,12 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
         flags |= L.EPI_GELU
     if dgelu_rc:
         flags |= L.EPI_DGELU_RC
+    if relu:
+        flags |= L.EPI_RELU
+    if drelu_aux is not None:       # gradient through a ReLU whose output is drelu_aux
+        flags |= L.EPI_DRELU
+        g.aux = drelu_aux.data_ptr() + aux_off * drelu_aux.element_size()
+        g.ldaux = drelu_aux.shape[-1]
     if ln_bwd is not None:      # (x, stats, gamma, dgamma, dbeta): the product is d(LayerNorm output); out = [resid +] LN'(product)
         x_ln, st_ln, gam, dgam, dbet = ln_bwd
         flags |= L.EPI_LNBWD
@@ -293,6 +299,36 @@ def wmsa_block_bwd(xn1, wpk, bias_t, dout, lsew, dqkv, dbias_t, B, H, W, Cc, hea
     """Attention backward of the fused block (bf16) with q / k / v recomputed from the saved LN1 output and the parameter pack."""
     _launch("sodt_wmsa_block_bwd", _p(xn1), _p(wpk), _p(bias_t), _p(dout), _p(lsew), _p(dqkv), _p(dbias_t),
             B, H, W, Cc, heads, ws, shift, dt_code(dout))
+
+
+# ---- super-resolution branch data movement (csrc/sr.hip)
+def bilinear_up2_fwd(x, y, B, H, W, Cc, ldy=None, ycol=0):
+    """y[:, ycol : ycol + C] = bilinear x2 (align_corners=True) of x [B*H*W][C]; y may be a wider [B*4HW][ldy] buffer."""
+    ldy = y.shape[-1] if ldy is None else ldy
+    _launch("sodt_bilinear_up2_fwd", x.data_ptr(), y.data_ptr() + ycol * y.element_size(), ldy, B, H, W, Cc, dt_code(x))
+
+
+def bilinear_up2_bwd(dy, dx, B, H, W, Cc, lddy=None, dycol=0, relu_out=None):
+    lddy = dy.shape[-1] if lddy is None else lddy
+    _launch("sodt_bilinear_up2_bwd", dy.data_ptr() + dycol * dy.element_size(), lddy, dx.data_ptr(), _p(relu_out), B, H, W, Cc, dt_code(dx))
+
+
+def pixel_shuffle2(src, dst, B, H, W, Cc, inverse=False):
+    """forward: src [B*H*W][4C] -> dst [B*2H*2W][C] (nn.PixelShuffle(2)); inverse: src [B*2H*2W][C] -> dst [B*H*W][4C]."""
+    _launch("sodt_pixel_shuffle2", src.data_ptr(), dst.data_ptr(), B, H, W, Cc, int(bool(inverse)), dt_code(src))
+
+
+def add_rows(dst, src, M, Cc, ldd=None, dcol=0, lds=None, scol=0):
+    _launch("sodt_add_rows", dst.data_ptr(), dst.shape[-1] if ldd is None else ldd, dcol, src.data_ptr(),
+            src.shape[-1] if lds is None else lds, scol, C.c_long(M), Cc, dt_code(dst))
+
+
+def nchw_f32_from_rows(rows, y, B, Cc, H, W):
+    _launch("sodt_nchw_f32_from_rows", rows.data_ptr(), rows.shape[-1], y.data_ptr(), B, Cc, H, W, dt_code(rows))
+
+
+def rows_from_nchw_f32(y, rows, B, Cc, H, W):
+    _launch("sodt_rows_from_nchw_f32", y.data_ptr(), rows.data_ptr(), rows.shape[-1], B, Cc, H, W, dt_code(rows))
 
 
 def frontend_fwd(rgb, ir_plane, ir_bstride, w, b, gamma, beta, out, B, S, ca_ws=1):

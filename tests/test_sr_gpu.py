@@ -1,0 +1,147 @@
+"""The super-resolution branch on the HIP kernels (sr.py: Decoder + EDSR = DeepLab, basics/models/deeplabedsr.py:35-73,
+sr_decoder_noBN_noD.py:6-45, edsr.py:55-102) against tests/golden/sr.pt, which holds what the reference's own classes produce on the
+procedural weights (oracle/gen_golden.py --only-sr): outputs, input gradients, every parameter's gradient norm and 64 strided gradient
+values.  f32 is the parity run (tight); bf16 is the throughput dtype (loose)."""
+import importlib
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# (output / input-gradient max error relative to the tensor's max magnitude, gradient-norm relative error)
+TOL = {torch.float32: (2e-4, 2e-4), torch.bfloat16: (6e-2, 6e-2)}
+TOL_DEEP = {torch.float32: (1e-3, 1e-3), torch.bfloat16: (1e-1, 1e-1)}       # 37 convolutions in sequence
+
+
+def _setup(name, dev, dt):
+    from oracle import ref_torch as R
+    S = importlib.import_module("small-object-detection-transformers_amd.sr")
+    g = torch.load(os.path.join(GOLD, "sr.pt"))[name]
+    sd = {k: v.float().contiguous().to(dev) for k, v in R.procedural_from_shapes(g["shapes"]).items()}
+    return R, S, g, sd
+
+
+def _rows(ops, x, dev, dt):
+    B, C, H, W = x.shape
+    r = torch.zeros(B * H * W, C, device=dev, dtype=dt)
+    ops.rows_from_nchw_f32(x.to(dev).contiguous(), r, B, C, H, W)
+    return r
+
+
+def _nchw(ops, r, B, C, H, W):
+    y = torch.empty(B, C, H, W, device=r.device, dtype=torch.float32)
+    ops.nchw_f32_from_rows(r, y, B, C, H, W)
+    return y
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / max(1e-9, float(b.abs().max()))
+
+
+def _check_grads(br, g, tol, what):
+    worst = 0.0
+    for k, v in g["gnorm"].items():
+        got = br.g[k]
+        n = float(got.double().norm())
+        assert abs(n - v) <= tol * (v + 1e-9), f"{what} {k}: grad norm {n:.6e} vs {v:.6e}"
+        sub = got.reshape(-1)[::max(1, got.numel() // 64)][:64]
+        e = float((sub.cpu() - g["gsub"][k]).abs().max()) / (float(g["gsub"][k].abs().max()) + 1e-6)
+        worst = max(worst, e)
+        assert e <= 4 * tol, f"{what} {k}: strided gradient values off by {e:.3e}"
+    return worst
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_sr_decoder_matches_reference_golden(ops, dev, dt):
+    R, S, g, sd = _setup("decoder", dev, dt)
+    low, x = g["inputs"]                        # (2, 16, 12, 10), (2, 32, 6, 5)
+    B, c1, H, W = low.shape
+    br = S.SRBranch(sd, dt)
+    d3 = br.decoder_forward([ops.SegSpec(_rows(ops, low, dev, dt))], [ops.SegSpec(_rows(ops, x, dev, dt))], B, H, W)
+    y = _nchw(ops, d3, B, 64, H, W)
+    to, tg = TOL[dt]
+    st = g["y_step"]
+    assert _rel(y[..., ::st, ::st], g["y_sub"]) <= to
+    gsel = R._hash01("sr:decoder", y.numel()).view(y.shape).float()
+    d_low, d_x = br.decoder_backward(_rows(ops, gsel, dev, dt))
+    torch.cuda.synchronize()
+    assert _rel(_nchw(ops, d_low, B, c1, H, W), g["dinputs"][0]) <= to
+    assert _rel(_nchw(ops, d_x, B, x.shape[1], H // 2, W // 2), g["dinputs"][1]) <= to
+    _check_grads(br, g, tg, "decoder")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_sr_edsr_matches_reference_golden(ops, dev, dt):
+    R, S, g, sd = _setup("edsr", dev, dt)
+    (x,) = g["inputs"]                          # (1, 64, 7, 6) -> (1, 4, 56, 48)
+    B, _, H, W = x.shape
+    br = S.SRBranch(sd, dt)
+    y = br.edsr_forward(_rows(ops, x, dev, dt), B, H, W)
+    to, tg = TOL[dt]
+    st = g["y_step"]
+    assert tuple(y.shape) == (B, 4, 8 * H, 8 * W)
+    assert _rel(y[..., ::st, ::st], g["y_sub"]) <= to
+    gsel = R._hash01("sr:edsr", y.numel()).view(y.shape).float().to(dev)
+    dx = br.edsr_backward(gsel.contiguous())
+    torch.cuda.synchronize()
+    assert _rel(_nchw(ops, dx, B, 64, H, W), g["dinputs"][0]) <= to
+    _check_grads(br, g, tg, "edsr")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_sr_deeplab_matches_reference_golden(ops, dev, dt):
+    """DeepLab(4, 128, 512, factor 2) as model.py:113-115 builds it (EDSR depth 16, 2.9 M parameters): 128 @ 16 x 16 and
+    512 @ 8 x 8 in, (1, 4, 128, 128) out; twice over, to show that the gradients accumulate and the buffers are reused."""
+    R, S, g, sd = _setup("deeplab", dev, dt)
+    low, x = g["inputs"]
+    B, c1, H, W = low.shape
+    br = S.SRBranch(sd, dt, dec="model_up.sr_decoder.", edsr="model_up.edsr.")
+    assert br.depth == 16
+    lr, xr = _rows(ops, low, dev, dt), _rows(ops, x, dev, dt)
+    to, tg = TOL_DEEP[dt]
+    st = g["y_step"]
+    for rep in range(2):
+        y = br.forward([ops.SegSpec(lr)], [ops.SegSpec(xr)], B, H, W)
+        assert tuple(y.shape) == (B, 4, 8 * H, 8 * W)
+        assert _rel(y[..., ::st, ::st], g["y_sub"]) <= to
+        gsel = R._hash01("sr:deeplab", y.numel()).view(y.shape).float().to(dev)
+        d_low, d_x = br.backward(gsel.contiguous())
+        torch.cuda.synchronize()
+        assert _rel(_nchw(ops, d_low, B, c1, H, W), g["dinputs"][0]) <= to
+        assert _rel(_nchw(ops, d_x, B, x.shape[1], H // 2, W // 2), g["dinputs"][1]) <= to
+        if rep == 0:
+            _check_grads(br, g, tg, "deeplab")
+            first = {k: v.clone() for k, v in br.g.items()}
+    for k, v in br.g.items():                    # the second pass added the same gradients again
+        assert float((v - 2 * first[k]).abs().max()) <= 1e-3 * (float(first[k].abs().max()) + 1e-9), k
+
+
+def test_sr_upsampled_low_level_view(ops, dev):
+    """The low-level input may be an upsampling VIEW (y[8] = Upsample(y7) in the head graph): SegSpec(shr=1) over the half-size
+    tensor equals materialising the nearest x2 copy first."""
+    S = importlib.import_module("small-object-detection-transformers_amd.sr")
+    from oracle import ref_torch as R
+    dt = torch.float32
+    shapes = {"sr_decoder." + k[len("sr_decoder."):]: v for k, v in S.sr_param_shapes(4, 16, 32).items() if k.startswith("sr_decoder.")}
+    sd = {k: v.float().contiguous().to(dev) for k, v in R.procedural_from_shapes(shapes).items()}
+    B, H, W = 2, 8, 12
+    g = torch.Generator().manual_seed(5)
+    half = torch.randn(B, 16, H // 2, W // 2, generator=g)
+    x = torch.randn(B, 32, H // 2, W // 2, generator=g)
+    full = half.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    a, b = S.SRBranch(sd, dt), S.SRBranch(sd, dt)
+    ya = a.decoder_forward([ops.SegSpec(_rows(ops, full, dev, dt))], [ops.SegSpec(_rows(ops, x, dev, dt))], B, H, W)
+    hv = _rows(ops, half, dev, dt)
+    yb = b.decoder_forward([ops.SegSpec(hv, 16, 0, 0, 0, 1, 1, H // 2, W // 2)], [ops.SegSpec(_rows(ops, x, dev, dt))], B, H, W)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    dy = torch.randn(B * H * W, 64, generator=g).to(dev)
+    da, _ = a.decoder_backward(dy)
+    db, _ = b.decoder_backward(dy)
+    torch.cuda.synchronize()
+    assert torch.equal(da, db)
+    for k in a.g:
+        assert _rel(b.g[k], a.g[k]) <= 1e-5, k
