@@ -125,17 +125,21 @@ class _EngineFn(torch.autograd.Function):
     def forward(ctx, engine, plan, x_rgb, x_ir, anchor):
         ctx.engine, ctx.plan = engine, plan
         ctx.inputs = (x_rgb, x_ir)
+        ctx.set_materialize_grads(False)         # an unused output (detection-only or SR-only loss) arrives as None, not zeros
         pred = engine._forward(plan, x_rgb, x_ir)
         ctx.gen = plan.gen
+        if engine.sr:
+            return pred, engine._sr_forward(plan)
         return pred
 
     @staticmethod
-    def backward(ctx, dpred):
+    def backward(ctx, dpred, dsr=None):
         if ctx.gen != ctx.plan.gen:
             raise RuntimeError("the activations this backward needs were overwritten by a later forward of the same "
                                "(batch, resolution, dtype, mode): call backward() before the next forward, or run the "
                                "extra forward under model.eval() / torch.no_grad() with a different mode")
-        ctx.engine._backward(ctx.plan, ctx.inputs[0], ctx.inputs[1], dpred.contiguous().float())
+        ctx.engine._backward(ctx.plan, ctx.inputs[0], ctx.inputs[1], None if dpred is None else dpred.contiguous().float(),
+                             None if dsr is None else dsr.contiguous().float())
         return None, None, None, None, None
 
 
@@ -157,6 +161,7 @@ class Engine:
         self.na, self.no, self.nc = det.na, det.no, det.nc
         self.det_np = (det.na * det.no + 15) // 16 * 16      # Detect GEMM width, zero-padded to a multiple of 16 (39 -> 48 at nc = 8)
         self.fused = not any(type(m).__name__ == "BatchNorm2d" for m in model.detect.modules())
+        self.sr = bool(getattr(model, "sr", False))
         self._check_head()
         self.plans: Dict[Tuple, Plan] = {}
         self.probes_fwd: Optional[dict] = None    # bench.py: {call index: (start event, end event)}
@@ -255,6 +260,19 @@ class Engine:
                                           "feature to exactly one consumer")
         self.head_units, self.head_rules, self.nd = units, rules, len(d) - 1
         self.det_name = f"detect.{self.nd}."
+        self.sr_taps = None
+        if self.sr:
+            # model_up(y[l1], y[l2]) (model.py:286) cannot run with the yaml's l1 / l2 = 4 / 8 (256 channels into the 128-channel
+            # conv1); the taps are the first feature-list entries with the channel counts and grids DeepLab(ch, c1, c2) needs:
+            # c1 on the stride-4 grid (low-level) and c2 on the stride-8 grid - y[8] and y[5] in models/model.yaml
+            mu = self.model.model_up
+            def first(cn, level):
+                for yi in sorted(vals):
+                    if vals[yi][1] == level and sum(c for _, c, _ in vals[yi][0]) == cn:
+                        return yi
+                raise NotImplementedError(f"sr=True: no feature-list entry has {cn} channels on the stride-{4 << level} grid")
+            self.sr_taps = (first(mu.c1, 0), first(mu.c2, 1))
+            self.sr_parts = (vals[self.sr_taps[0]][0], vals[self.sr_taps[1]][0])
 
     def _unit_out_name(self, u):
         return f"h{u['k']}" + {"Conv": ".y", "C3": ".cv3.y", "SPP": ".cv2.y"}[u["kind"]]
@@ -267,7 +285,7 @@ class Engine:
         # contiguous slices at the end of the buffer (ddp.py): [front end | pos/patch embed | stage 1 | PatchMerging 1,
         # neck 1 | stage 2 | PatchMerging 2, neck 2 | stage 3 | neck 3 | head]
         groups = [E + "pos_embed", E + "patch_embed.", E + "stage1.", E + "pmerging1.", E + "neck1.", E + "stage2.",
-                  E + "pmerging2.", E + "neck2.", E + "stage3.", E + "neck3.", "detect."]
+                  E + "pmerging2.", E + "neck2.", E + "stage3.", E + "neck3.", "detect.", "model_up."]
         seen = set(order)
         rest = []
         for gname in groups:
@@ -289,7 +307,7 @@ class Engine:
         self.ddp_split = offs[next(n for n in self.grad_order if n.startswith(E + "pmerging1."))]
         self.ddp_split3 = offs[next(n for n in self.grad_order if n.startswith(E + "stage3."))]
         assert self.ddp_split < self.ddp_split3 and all(
-            n.startswith((E + "stage3.", E + "neck3.", "detect.")) for n in self.grad_order if offs[n] >= self.ddp_split3)
+            n.startswith((E + "stage3.", E + "neck3.", "detect.", "model_up.")) for n in self.grad_order if offs[n] >= self.ddp_split3)
         assert all(not n.startswith((E + "stage1.", E + "patch_embed.", E + "pos_embed", E + "channel_embed", E + "chan_block"))
                    for n in self.grad_order if offs[n] >= self.ddp_split)
         fe = offs[E + "channel_embed_r.proj.weight"]
@@ -382,8 +400,8 @@ class Engine:
             o = self.grad_offsets[n]
             return mirror[o: o + self.params[n].numel()].view(shape)
         for n, p in self.params.items():
-            if p.dim() < 2 or "relative_position_bias_table" in n or "channel_embed" in n:
-                continue
+            if p.dim() < 2 or "relative_position_bias_table" in n or "channel_embed" in n or n.startswith("model_up."):
+                continue        # (model_up: sr.SRBranch lays its own weights out)
             if n == E + "pos_embed":
                 t = p.shape[1]
                 w[n] = mview(n, (t * t, 192))
@@ -477,11 +495,16 @@ class Engine:
                 self.plans.pop(next(iter(self.plans)))          # dicts keep insertion order: the first key is the LRU one
             plan = Plan(B, S, dt, training, self.dev)
         self.plans[key] = plan                                   # (re)insert as most recently used
+        out_sr = None
         if training and torch.is_grad_enabled():
             pred = _EngineFn.apply(self, plan, x_rgb, x_ir, self._anchor)
+            if self.sr:
+                pred, out_sr = pred
         else:
             pred = self._forward(plan, x_rgb, x_ir)
-        return pred, self._features(plan)
+            if self.sr and training:                              # model.py:284-287: the branch runs in training mode only
+                out_sr = self._sr_forward(plan)
+        return pred, self._features(plan), out_sr
 
     def decode(self, pred):
         B, na, ny, nx, no = pred.shape
@@ -919,8 +942,71 @@ class Engine:
         ops.gemm_nt([SegSpec(dz1)], wT[pname + "cv1.conv.weight"], din, M, c1, c_)
         return din
 
+    # ================================================================== super-resolution branch (model.py:284-287)
+    def _ref_buf(self, plan, ref):
+        return plan.bufs[f"f{ref[1]}"] if ref[0] == "enc" else plan.bufs[self._unit_out_name(self._unit(ref[1]))]
+
+    def _sr_forward(self, plan: Plan):
+        """output_sr = model_up(low-level, deep) on the tapped features: live launches (sr.SRBranch; its weights are re-laid out
+        from the masters every call).  The taps are K-segment views of the head's buffers - an Upsample / Concat entry is index
+        arithmetic here too."""
+        from .sr import SRBranch
+        B, t = plan.B, plan.S // 4
+        br = getattr(plan, "sr", None)
+        if br is None:
+            names = [n for n in self.params if n.startswith("model_up.")]
+            br = plan.sr = SRBranch({n: self.params[n] for n in names}, plan.dt, {n: self.g[n] for n in names},
+                                    dec="model_up.sr_decoder.", edsr="model_up.edsr.")
+        else:
+            br.prepare()
+        def segs(parts, level):
+            h = t >> level
+            return [SegSpec(self._ref_buf(plan, ref), c, 0, 0, 0, 1, shr, h >> shr, h >> shr) for ref, c, shr in parts]
+        return br.forward(segs(self.sr_parts[0], 0), segs(self.sr_parts[1], 1), B, t, t)
+
+    def _sr_backward(self, plan: Plan, dsr):
+        """SR gradients: parameters into the flat buffer, inputs into plan.sr's dense buffers (zero when the SR output took no part
+        in the loss); the recorded head backward adds them to the tapped features' gradients (_backward_main: sr_extra)."""
+        br = plan.sr
+        if dsr is None:
+            for k in ("g.low", "g.x"):
+                if k in br.bufs:
+                    ops.zero_(br.bufs[k])
+            return
+        br.backward(dsr)
+
+    def _sr_extra(self, plan: Plan):
+        """ref -> [(dense gradient buffer, ld, column offset, channels, shr)]: what the SR branch adds to d(feature)."""
+        B, t = plan.B, plan.S // 4
+        br = plan.sr
+        c1 = sum(c for _, c, _ in self.sr_parts[0])
+        c2 = sum(c for _, c, _ in self.sr_parts[1])
+        d_low = br._buf("g.low", (B * t * t, c1))
+        d_x = br._buf("g.x", (B * (t // 2) ** 2, c2))
+        extra: Dict[tuple, list] = {}
+        for parts, buf, level in ((self.sr_parts[0], d_low, 0), (self.sr_parts[1], d_x, 1)):
+            coff = 0
+            for ref, c, shr in parts:
+                extra.setdefault(ref, []).append((buf, buf.shape[1], coff, c, shr, t >> level))
+                coff += c
+        return extra
+
+    def _add_extra(self, plan: Plan, extra, ref, target):
+        """target (buffer, ld, column offset) += the SR branch's gradient for feature `ref` (summed over the 2^shr x 2^shr children
+        where the tap was an upsampled view)."""
+        B = plan.B
+        dst, ld, off = target
+        for i, (buf, lds, coff, c, shr, H) in enumerate(extra.get(ref, ())):
+            if shr == 0:
+                ops.add_rows(dst, buf, B * H * H, c, ldd=ld, dcol=off, lds=lds, scol=coff)
+            else:
+                Hs = H >> shr
+                tmp = plan.buf(f"sr.dup.{ref[0]}{ref[1]}.{i}", (B * Hs * Hs, c))
+                ops.gather_sum_rows(buf, lds, tmp, c, B, Hs, Hs, shr, c, d_off=coff)
+                ops.add_rows(dst, tmp, B * Hs * Hs, c, ldd=ld, dcol=off)
+
     # ================================================================== backward
-    def _backward(self, plan: Plan, x_rgb, x_ir, dpred):
+    def _backward(self, plan: Plan, x_rgb, x_ir, dpred, dsr=None):
         if self.fused or not plan.training:
             raise RuntimeError("backward needs a training-mode, un-fused model")
         P = self._prep_for(plan.dt)
@@ -934,7 +1020,12 @@ class Engine:
             self.ddp.begin_backward(self.flat_grad, fresh)
         # (1) Detect backward: live (dpred pointer changes)
         dzd = plan.buf("g.dzd", (T1, self.det_np))
-        ops.detect_unpermute(dpred, dzd, self.det_np, B, t * t, self.na, self.no)
+        if dpred is None:                            # SR-only loss
+            ops.zero_(dzd)
+        else:
+            ops.detect_unpermute(dpred, dzd, self.det_np, B, t * t, self.na, self.no)
+        if self.sr:
+            self._sr_backward(plan, dsr)             # live too: its input gradients land in plan.sr's buffers
         overlap = False
         if plan.bwd_main is None:
             with ops.Recorder() as rec:
@@ -1005,11 +1096,13 @@ class Engine:
         # ---- head units in reverse: every unit returns d(its concatenated input) [M][c1]; the gradient of an Upsample /
         #      Concat input is a column slice of it (nearest x2^shr upsample: summed over the 2^shr x 2^shr children)
         gout = {("unit", hu["k"]): (dyd, cd, 0)}                     # ref -> (buffer, ld, column offset)
+        extra = self._sr_extra(plan) if self.sr else {}
         for u in reversed(self.head_units):
             H = t >> u["level"]
             M = B * H * H
             tag = f"h{u['k']}"
             dy, ld, off = gout.pop(("unit", u["k"]))
+            self._add_extra(plan, extra, ("unit", u["k"]), (dy, ld, off))
             if u["kind"] == "Conv":
                 dz = self._conv_bwd(plan, tag, dy, ld, off)
                 din = plan.buf(tag + ".din", (M, u["c1"]))
@@ -1033,6 +1126,8 @@ class Engine:
                     ops.gather_sum_rows(din, u["c1"], dsrc, c, B, Hs, Hs, shr, c, d_off=coff)
                     gout[ref] = (dsrc, c, 0)
                 coff += c
+        for j in range(3):
+            self._add_extra(plan, extra, ("enc", j), gout[("enc", j)])
         (gf0, ld0, off0), (gf1, ld1, off1), (gf2, ld2, off2) = gout[("enc", 0)], gout[("enc", 1)], gout[("enc", 2)]
         # where the head's backward ends and the encoder's begins, and the buffers the head left d(f0), d(f1), d(f2) in
         # (token-major rows, `ld` columns, the feature's columns at `off`): replay_encoder_backward re-runs the rest from there

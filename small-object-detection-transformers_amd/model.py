@@ -337,10 +337,7 @@ class Model(nn.Module):
             self.yaml_file = Path(path).name
             with open(path) as f:
                 self.yaml = yaml.load(f, Loader=yaml.SafeLoader)
-        if sr:
-            raise NotImplementedError("the super-resolution branch is unreachable in the reference "
-                                      "(model.py:111 imports a non-existent package; SURVEY.md section 8 row 5)")
-        self.sr = False
+        self.sr = bool(sr)
         ch = self.yaml["ch"] = self.yaml.get("ch", ch)
         if nc and nc != self.yaml["nc"]:
             self.yaml["nc"] = nc
@@ -348,6 +345,18 @@ class Model(nn.Module):
             self.yaml["anchors"] = round(anchors)
         self.image_encoder, self.save1 = parse_model(deepcopy(self.yaml), "backbone", ch=[ch])
         self.detect, self.save2 = parse_model(deepcopy(self.yaml), "head", ch=[ch])
+        if self.sr:
+            # model.py:109-117.  The reference cannot get here (it imports `models.deeplabedsr`, which does not exist, and its
+            # l1 / l2 = 4 / 8 would feed 256 channels into the 128-channel conv1: SURVEY.md section 8, config reality row 5);
+            # this builds what the constructor describes - DeepLab(3 or 4, c1, c2, factor) - and the engine taps the first
+            # feature-list entries that HAVE c1 channels on the stride-4 grid and c2 channels on the stride-8 grid (y[8] and
+            # y[5] in models/model.yaml).  An interpretation: graph parity unpinned; the modules themselves are pinned
+            # (tests/golden/sr.pt).
+            from .sr import DeepLab
+            if factor != 2:
+                raise NotImplementedError("the super-resolution branch is built for factor=2 (Train.py:98 down_factor default)")
+            self.model_up = DeepLab(3 if input_mode in ("IR", "RGB") else 4, self.yaml["c1"], self.yaml["c2"], factor=factor)
+            self.l1, self.l2 = self.yaml["l1"], self.yaml["l2"]
         m = self.detect[-1]
         if isinstance(m, Detect):
             m.stride = torch.tensor([4.])                       # model.py:130
@@ -446,8 +455,10 @@ class Model(nn.Module):
         if dt is None:
             dt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
         training = self.training or self.export
-        pred, feats = eng.run(x, ir, dt, training)
+        pred, feats, out_sr = eng.run(x, ir, dt, training)
         if training:
+            if self.sr:                                          # model.py:203-205
+                return [pred], out_sr, feats + [[pred]]
             return [pred], feats + [[pred]]
         z = eng.decode(pred)
         if getattr(self, "_nms", None) is not None:

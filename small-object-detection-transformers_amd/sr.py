@@ -55,6 +55,43 @@ def sr_param_shapes(ch: int, c1: int, c2: int, depth: int = 16, width: int = 64)
     return s
 
 
+class DeepLab(torch.nn.Module):
+    """Parameter container with the reference DeepLab's module tree (deeplabedsr.py:35-58 -> Decoder sr_decoder_noBN_noD.py:7-25,
+    EDSR edsr.py:55-80), so that state_dict keys, registration order and initial statistics match: Decoder convolutions
+    kaiming_normal_ (sr_decoder_noBN_noD.py:60-64), EDSR convolutions nn.Conv2d's default.  It is never called: the branch runs
+    inside the engine (SRBranch)."""
+
+    def __init__(self, ch, c1=128, c2=512, factor=2, depth=16, width=64):
+        super().__init__()
+        nn = torch.nn
+        conv3 = lambda i, o, bias=True: nn.Conv2d(i, o, 3, padding=1, bias=bias)
+        dec = nn.Module()
+        dec.conv1 = nn.Conv2d(c1, c1 // 2, 1, bias=False)
+        dec.conv2 = nn.Conv2d(c2, c2 // 2, 1, bias=False)
+        dec.last_conv = nn.Sequential(conv3((c1 + c2) // 2, 256, False), nn.ReLU(), conv3(256, 128, False), nn.ReLU(), nn.Conv2d(128, 64, 1))
+        for m in dec.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+        self.sr_decoder = dec
+        ed = nn.Module()
+        ed.head = nn.Sequential(conv3(64, width))
+        blocks = []
+        for _ in range(depth):
+            rb = nn.Module()
+            rb.body = nn.Sequential(conv3(width, width), nn.ReLU(True), conv3(width, width))
+            blocks.append(rb)
+        ed.body = nn.Sequential(*blocks, conv3(width, width))
+        up = []
+        for _ in range(3):                                   # x8 = three (conv to 4 n_feat, PixelShuffle 2) stages (edsr.py:19-24)
+            up += [conv3(width, 4 * width), nn.PixelShuffle(2)]
+        ed.tail = nn.Sequential(nn.Sequential(*up), conv3(width, ch))
+        self.edsr = ed
+        self.factor, self.ch, self.c1, self.c2 = factor, ch, c1, c2
+
+    def forward(self, low_level_feat, x):
+        raise RuntimeError("model_up runs inside the MI355X engine (Model.forward with sr=True); it has no torch forward")
+
+
 class _Conv:
     """GEMM views of one Conv2d: w [Np][taps*Cin] (forward), wT [Cin][taps*Np] (input gradient) in the run dtype; Np = Cout rounded
     up to 8 (zero rows / columns: the closing 64 -> ch convolution has 3 or 4 outputs).  The forward GEMM runs at N = Cout over the
@@ -87,7 +124,7 @@ class SRBranch:
             c.np_ = (c.cout + 7) // 8 * 8
             c.bias = params.get(c.name + ".bias")
             if c.taps == 1 and c.np_ == c.cout and dt == torch.float32:
-                c.w = v.view(c.cout, c.cin)
+                c.w = v.detach().view(c.cout, c.cin)
             else:
                 c.w = torch.zeros(c.np_, c.taps * c.cin, device=self.dev, dtype=dt)                 # [n][tap*Cin + c]
                 descs.append(self._desc(v, c.w, (c.cout, c.cin, c.taps), (0, 2, 1), c.taps * c.cin, 0))

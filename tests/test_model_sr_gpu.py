@@ -1,0 +1,98 @@
+"""Model(sr=True): the super-resolution branch wired into the engine (model.py:109-117, :203-205, :284-287).  The reference cannot
+reach this configuration (SURVEY.md section 8, config reality row 5), so the comparison is against the ORACLE's restatement of what
+the constructor describes - DeepLab(4, c1, c2) on y[8] (128 @ t) and y[5] (512 @ t/2) - with autograd on the CPU: graph parity
+unpinned, module parity pinned by tests/test_sr_gpu.py."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def build(dev, img, nc=8):
+    from oracle import ref_torch as R
+    M = importlib.import_module("small-object-detection-transformers_amd.model")
+    S = importlib.import_module("small-object-detection-transformers_amd.sr")
+    cfg = dict(nc=nc, depth_multiple=0.33, width_multiple=0.5, anchors=[[10, 13, 16, 30, 33, 23]], l1=4, l2=8, c1=128, c2=512,
+               backbone=[[-1, 1, "ImageEncoderViT", [img, 6, 192, 4, 256, 4]]],
+               head=[[2, 1, "Conv", [512, 1, 1]], [-1, 1, "nn.Upsample", [None, 2, "nearest"]], [[-1, 1], 1, "Concat", [1]],
+                     [-1, 3, "C3", [512, False]], [-1, 1, "Conv", [256, 1, 1]], [-1, 1, "nn.Upsample", [None, 2, "nearest"]],
+                     [[-1, 0], 1, "Concat", [1]], [-1, 3, "C3", [256, False]], [[10], 1, "Detect", ["nc", "anchors"]]])
+    model = M.Model(cfg, input_mode="RGB+IR", ch_steam=3, ch=128, nc=nc, sr=True, factor=2)
+    sd = R.procedural_state_dict(img, nc)
+    sd.update(R.procedural_from_shapes({"model_up." + k: v for k, v in S.sr_param_shapes(4, 128, 512).items()}))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("relative_position_index" in k or "attn_mask" in k) for k in missing), missing
+    return model.to(dev), sd
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm()) / max(1e-12, float(b.norm()))
+
+
+def test_sr_model_constructs_like_the_reference(dev):
+    model, sd = build(dev, 128)
+    assert model.sr and (model.l1, model.l2) == (4, 8)
+    keys = [k for k in model.state_dict() if k.startswith("model_up.")]
+    assert len(keys) == 82 and keys[0] == "model_up.sr_decoder.conv1.weight" and keys[-1] == "model_up.edsr.tail.1.bias"
+    assert sum(p.numel() for p in model.model_up.parameters()) == 2880708
+    model.eval()
+    from oracle import ref_torch as R
+    x_rgb, x_ir = R.synthetic_inputs(1, 128, seed=3)
+    out = model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
+    assert len(out) == 3                                       # eval: (z, [pred], y) - the branch is training-only (model.py:284)
+
+
+@pytest.mark.parametrize("dtype,tol_out,tol_grad", [(torch.float32, 1e-3, 3e-3), (torch.bfloat16, 8e-2, 0.2)])
+@pytest.mark.parametrize("which", ["both", "sr_only", "det_only"])
+def test_sr_train_step_vs_oracle(dev, dtype, tol_out, tol_grad, which):
+    from oracle import ref_torch as R
+    S, B = 128, 2
+    model, sd = build(dev, S)
+    model.compute_dtype = dtype
+    model.train()
+    x_rgb, x_ir = R.synthetic_inputs(B, S, seed=1)
+    pred, out_sr, y = model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
+    assert tuple(out_sr.shape) == (B, 4, 2 * S, 2 * S) and out_sr.dtype == torch.float32
+    gsel = R._hash01("gsel", pred[0].numel()).view(pred[0].shape).float()
+    ssel = R._hash01("ssel", out_sr.numel()).view(out_sr.shape).float() * 0.05
+    loss = 0
+    if which != "sr_only":
+        loss = loss + (pred[0] * gsel.to(dev)).sum()
+    if which != "det_only":
+        loss = loss + (out_sr * ssel.to(dev)).sum()
+    loss.backward()
+
+    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "anchor" not in k) for k, v in sd.items()}
+    opred, oy = R.model_forward(osd, x_rgb, x_ir, True, {})
+    assert tuple(oy[8].shape) == (B, 128, S // 4, S // 4) and tuple(oy[5].shape) == (B, 512, S // 8, S // 8)
+    osr = R.deeplab_sr(osd, "model_up.", oy[8], oy[5], 2)
+    oloss = 0
+    if which != "sr_only":
+        oloss = oloss + (opred[0] * gsel).sum()
+    if which != "det_only":
+        oloss = oloss + (osr * ssel).sum()
+    oloss.backward()
+    assert rel_l2(out_sr, osr) <= tol_out, f"output_sr: {rel_l2(out_sr, osr):.3e}"
+    assert rel_l2(pred[0], opred[0]) <= tol_out
+    gmed = sorted(float(osd[n].grad.double().norm()) for n, _ in model.named_parameters() if osd[n].grad is not None)
+    gmed = gmed[len(gmed) // 4]
+    allr = []
+    for n, p in model.named_parameters():
+        og = osd[n].grad
+        if og is None or (which == "det_only" and n.startswith("model_up.")) or (which == "sr_only" and float(og.abs().max()) == 0.0):
+            # parameters outside the loss's graph: zero (or no) gradient on both sides
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0 or which == "sr_only", n
+            continue
+        assert p.grad is not None, n
+        if n == "image_encoder.stage3.0.mlp.fc2.bias":      # zero in exact arithmetic (tests/test_model_gpu.py)
+            continue
+        d = float((p.grad.double().cpu() - og.double()).norm())
+        allr.append((d / (float(og.double().norm()) + 1e-2 * gmed + 1e-12), n))
+    allr.sort(reverse=True)
+    assert allr and allr[0][0] <= tol_grad, f"worst relative gradient errors {allr[:6]}"
+    if which != "det_only":
+        assert any(n.startswith("model_up.") for _, n in allr)

@@ -10,15 +10,16 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-# (output / input-gradient max error relative to the tensor's max magnitude, gradient-norm relative error)
-TOL = {torch.float32: (2e-4, 2e-4), torch.bfloat16: (6e-2, 6e-2)}
-TOL_DEEP = {torch.float32: (1e-3, 1e-3), torch.bfloat16: (1e-1, 1e-1)}       # 37 convolutions in sequence
+# (output / input-gradient error - see _rel for the metric per dtype -, gradient-norm relative error)
+TOL = {torch.float32: (2e-4, 2e-4), torch.bfloat16: (4e-2, 4e-2)}
+TOL_DEEP = {torch.float32: (1e-3, 1e-3), torch.bfloat16: (8e-2, 8e-2)}       # 37 convolutions in sequence
 
 
 def _setup(name, dev, dt):
     from oracle import ref_torch as R
     S = importlib.import_module("small-object-detection-transformers_amd.sr")
     g = torch.load(os.path.join(GOLD, "sr.pt"))[name]
+    _rel.l2 = dt == torch.bfloat16
     sd = {k: v.float().contiguous().to(dev) for k, v in R.procedural_from_shapes(g["shapes"]).items()}
     return R, S, g, sd
 
@@ -37,8 +38,15 @@ def _nchw(ops, r, B, C, H, W):
 
 
 def _rel(a, b):
+    """f32: max error over the tensor's max magnitude.  bf16: relative L2 error - single elements move by whole terms when a
+    ReLU input within bf16 rounding of zero changes sign, which says nothing about the kernels."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if _rel.l2:
+        return float((a - b).norm()) / max(1e-9, float(b.norm()))
     return float((a - b).abs().max()) / max(1e-9, float(b.abs().max()))
+
+
+_rel.l2 = False
 
 
 def _check_grads(br, g, tol, what):
@@ -48,7 +56,7 @@ def _check_grads(br, g, tol, what):
         n = float(got.double().norm())
         assert abs(n - v) <= tol * (v + 1e-9), f"{what} {k}: grad norm {n:.6e} vs {v:.6e}"
         sub = got.reshape(-1)[::max(1, got.numel() // 64)][:64]
-        e = float((sub.cpu() - g["gsub"][k]).abs().max()) / (float(g["gsub"][k].abs().max()) + 1e-6)
+        e = _rel(sub, g["gsub"][k])
         worst = max(worst, e)
         assert e <= 4 * tol, f"{what} {k}: strided gradient values off by {e:.3e}"
     return worst
@@ -125,6 +133,7 @@ def test_sr_upsampled_low_level_view(ops, dev):
     S = importlib.import_module("small-object-detection-transformers_amd.sr")
     from oracle import ref_torch as R
     dt = torch.float32
+    _rel.l2 = False
     shapes = {"sr_decoder." + k[len("sr_decoder."):]: v for k, v in S.sr_param_shapes(4, 16, 32).items() if k.startswith("sr_decoder.")}
     sd = {k: v.float().contiguous().to(dev) for k, v in R.procedural_from_shapes(shapes).items()}
     B, H, W = 2, 8, 12
