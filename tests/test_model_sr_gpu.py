@@ -46,9 +46,35 @@ def test_sr_model_constructs_like_the_reference(dev):
     assert len(out) == 3                                       # eval: (z, [pred], y) - the branch is training-only (model.py:284)
 
 
-@pytest.mark.parametrize("dtype,tol_out,tol_grad", [(torch.float32, 1e-3, 3e-3), (torch.bfloat16, 8e-2, 0.2)])
+def _oracle_step(R, sd, x_rgb, x_ir, gsel, ssel, which, emulate_bf16_sr, monkeypatch):
+    """pred, output_sr and every parameter's gradient from the oracle on the CPU; emulate_bf16_sr: the SR branch's convolutions
+    with operands / results rounded to bf16 both ways (tests/test_sr_gpu.py: what bf16 storage does to that branch)."""
+    from test_sr_gpu import _RoundBf16
+    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "anchor" not in k) for k, v in sd.items()}
+    opred, oy = R.model_forward(osd, x_rgb, x_ir, True, {})
+    B, S = x_rgb.shape[0], x_rgb.shape[-1]
+    assert tuple(oy[8].shape) == (B, 128, S // 4, S // 4) and tuple(oy[5].shape) == (B, 512, S // 8, S // 8)
+    with monkeypatch.context() as mp:
+        if emulate_bf16_sr:
+            conv, rq = R.F.conv2d, _RoundBf16.apply
+            mp.setattr(R.F, "conv2d", lambda x, w, b=None, *a, **k: rq(conv(rq(x), rq(w), b, *a, **k)))
+        osr = R.deeplab_sr(osd, "model_up.", oy[8], oy[5], 2)
+    oloss = 0
+    if which != "sr_only":
+        oloss = oloss + (opred[0] * gsel).sum()
+    if which != "det_only":
+        oloss = oloss + (osr * ssel).sum()
+    oloss.backward()
+    return opred[0].detach(), osr.detach(), {k: v.grad for k, v in osd.items() if v.requires_grad}
+
+
+@pytest.mark.parametrize("dtype,tol_out,tol_grad", [(torch.float32, 1e-3, 1e-2), (torch.bfloat16, 8e-2, 0.17)])
 @pytest.mark.parametrize("which", ["both", "sr_only", "det_only"])
-def test_sr_train_step_vs_oracle(dev, dtype, tol_out, tol_grad, which):
+def test_sr_train_step_vs_oracle(dev, dtype, tol_out, tol_grad, which, monkeypatch):
+    """bf16: the gradient that enters the encoder through 37 convolutions and 19 ReLUs of the SR branch carries that branch's bf16
+    storage error (ReLU inputs within rounding of zero change sign: 18 % on the branch's input gradients in the emulated-bf16
+    oracle, tests/test_sr_gpu.py), so the bound per parameter is 1.5 x what the oracle with an emulated-bf16 SR branch shows +
+    the bf16 bound of the detection-only step (tests/test_model_gpu.py: 0.17)."""
     from oracle import ref_torch as R
     S, B = 128, 2
     model, sd = build(dev, S)
@@ -66,33 +92,29 @@ def test_sr_train_step_vs_oracle(dev, dtype, tol_out, tol_grad, which):
         loss = loss + (out_sr * ssel.to(dev)).sum()
     loss.backward()
 
-    osd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "anchor" not in k) for k, v in sd.items()}
-    opred, oy = R.model_forward(osd, x_rgb, x_ir, True, {})
-    assert tuple(oy[8].shape) == (B, 128, S // 4, S // 4) and tuple(oy[5].shape) == (B, 512, S // 8, S // 8)
-    osr = R.deeplab_sr(osd, "model_up.", oy[8], oy[5], 2)
-    oloss = 0
-    if which != "sr_only":
-        oloss = oloss + (opred[0] * gsel).sum()
-    if which != "det_only":
-        oloss = oloss + (osr * ssel).sum()
-    oloss.backward()
-    assert rel_l2(out_sr, osr) <= tol_out, f"output_sr: {rel_l2(out_sr, osr):.3e}"
-    assert rel_l2(pred[0], opred[0]) <= tol_out
-    gmed = sorted(float(osd[n].grad.double().norm()) for n, _ in model.named_parameters() if osd[n].grad is not None)
+    opred, osr, og_all = _oracle_step(R, sd, x_rgb, x_ir, gsel, ssel, which, False, monkeypatch)
+    emu = None
+    if dtype == torch.bfloat16 and which != "det_only":
+        emu = _oracle_step(R, sd, x_rgb, x_ir, gsel, ssel, which, True, monkeypatch)[2]
+    assert rel_l2(out_sr.detach(), osr) <= tol_out, f"output_sr: {rel_l2(out_sr.detach(), osr):.3e}"
+    assert rel_l2(pred[0].detach(), opred) <= tol_out
+    gmed = sorted(float(v.double().norm()) for v in og_all.values() if v is not None)
     gmed = gmed[len(gmed) // 4]
     allr = []
     for n, p in model.named_parameters():
-        og = osd[n].grad
-        if og is None or (which == "det_only" and n.startswith("model_up.")) or (which == "sr_only" and float(og.abs().max()) == 0.0):
-            # parameters outside the loss's graph: zero (or no) gradient on both sides
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0 or which == "sr_only", n
+        og = og_all.get(n)
+        if og is None or float(og.abs().max()) == 0.0:
+            # outside the loss's graph (model_up under a detection-only loss, the head under an SR-only loss past its taps)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         assert p.grad is not None, n
         if n == "image_encoder.stage3.0.mlp.fc2.bias":      # zero in exact arithmetic (tests/test_model_gpu.py)
             continue
-        d = float((p.grad.double().cpu() - og.double()).norm())
-        allr.append((d / (float(og.double().norm()) + 1e-2 * gmed + 1e-12), n))
+        den = float(og.double().norm()) + 1e-2 * gmed + 1e-12
+        r = float((p.grad.double().cpu() - og.double()).norm()) / den
+        bound = tol_grad if emu is None else tol_grad + 1.5 * float((emu[n].double() - og.double()).norm()) / den
+        allr.append((r / bound, r, bound, n))
     allr.sort(reverse=True)
-    assert allr and allr[0][0] <= tol_grad, f"worst relative gradient errors {allr[:6]}"
+    assert allr and allr[0][0] <= 1.0, f"worst gradient errors (error / bound, error, bound, name) {allr[:6]}"
     if which != "det_only":
-        assert any(n.startswith("model_up.") for _, n in allr)
+        assert any(n.startswith("model_up.") for *_, n in allr)
