@@ -113,8 +113,14 @@ def test_model_has_no_cpu_path_and_is_copyable(M):
     assert m2._engine is None and len(m2.state_dict()) == 273
     m3 = pickle.loads(pickle.dumps(m))     # checkpoints pickle the module object
     assert torch.equal(m3.detect[8].m[0].bias, m.detect[8].m[0].bias)
+    # sr=True builds the reference's DeepLab(4, c1, c2) parameter tree (model.py:109-117); its 82 tensors follow the detector's
+    ms = M.Model("model.yaml", input_mode="RGB+IR", ch_steam=3, ch=128, nc=8, sr=True)
+    keys = list(ms.state_dict())
+    assert len(keys) == 273 + 82 and keys[273] == "model_up.sr_decoder.conv1.weight" and (ms.l1, ms.l2) == (4, 8)
+    with pytest.raises(RuntimeError, match="inside the MI355X engine"):
+        ms.model_up(x, x)
     with pytest.raises(NotImplementedError):
-        M.Model("model.yaml", input_mode="RGB+IR", sr=True)
+        M.Model("model.yaml", input_mode="RGB+IR", sr=True, factor=4)
 
 
 def test_fuse_matches_reference_formula(M):
