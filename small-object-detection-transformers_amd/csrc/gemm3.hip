@@ -47,7 +47,10 @@ constexpr int T3_BIASOFF = T3_SEGOFF + 448;         // f32 bias[N], N <= 3072 (r
 constexpr int T3_MAXBIAS = 3072;                    //  an ordinary global load there would drain the DMA queue every tile)
 constexpr int T3_LDS = T3_BIASOFF + T3_MAXBIAS * 4;
 
-__device__ uint4 g_zero16;                          // DMA source of rows outside the image / beyond M
+// DMA source of rows outside the image / beyond M.  8 KiB: such a row's source pointer advances by one K-step (128 B) per stage like
+// every other row's, up to the end of its K-segment (klen <= T3_MAXKLEN elements)
+__device__ uint4 g_zero16[512];
+constexpr int T3_MAXKLEN = (8192 - 256) / 2;
 
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_void*)p; }
 
@@ -86,6 +89,18 @@ __device__ __forceinline__ Seg3 load_seg3(uint32_t table, int i) {
   return s;
 }
 
+// the same entry for the whole wave (i uniform): kept in SGPRs - the NT K-loop compares against klen every stage
+__device__ __forceinline__ Seg3 load_seg3_uniform(uint32_t table, int i) {
+  const Seg3 v = load_seg3(table, i);
+  auto sc = [](int x) { return (int)__builtin_amdgcn_readfirstlane(x); };
+  Seg3 s;
+  const uint64_t pv = (uint64_t)(uintptr_t)v.p;
+  s.p = (const unsigned char*)(((uint64_t)(unsigned)sc((int)(pv >> 32)) << 32) | (unsigned)sc((int)pv));
+  s.ld = sc(v.ld); s.klen = sc(v.klen); s.dy = sc(v.dy); s.dx = sc(v.dx);
+  s.mul = sc(v.mul); s.shr = sc(v.shr); s.Hi = sc(v.Hi); s.Wi = sc(v.Wi);
+  return s;
+}
+
 __device__ __forceinline__ long seg3_row(const Seg3& s, bool ok, int b, int y, int x, int spatial, long m) {
   if (!ok) return -1;
   if (!spatial) return m;
@@ -101,7 +116,7 @@ __device__ __forceinline__ long seg3_row(const Seg3& s, bool ok, int b, int y, i
 template <int CF, bool OSC = false>
 __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: LDS-DMA destinations stay in SGPRs)
   const int wr = wid >> 1, wc = wid & 1;
   const int fi = lane & 15, fg = lane >> 4;
   const uint32_t lbase = lds_addr(dsm);
@@ -134,15 +149,28 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   if (total == 0) return;
   const int hw = g.a.Ho * g.a.Wo;
   const int spatial = g.a.spatial;
-  const unsigned char* zero = (const unsigned char*)&g_zero16;
+  const unsigned char* zero = (const unsigned char*)g_zero16;
 
-  // ---- A issue state: 4 rows per thread and stage (wave-instruction q covers tile rows 32 wid + 8 q .. + 7)
+  // ---- A issue state: 4 rows per thread and stage (wave-instruction q covers tile rows 32 wid + 8 q .. + 7).  The K-loop
+  //      carries one source POINTER per row (re-derived only when the tile or the K-segment changes) and advances it by one
+  //      K-step per stage: one 64-bit VALU add per DMA instruction (the row * ld + offset form cost ~10, and the two waves of
+  //      a SIMD run their address arithmetic and their MFMAs in the same phases: pmc r04, VALU 3.3 per MFMA on a plain GEMM)
   const int arow0 = 32 * wid + (lane >> 3);                    // + 8 q
   const int acb0 = ((lane & 7) ^ ((lane >> 4) & 3)) << 4;      // swizzled source chunk (bytes), q even
   const int acb1 = ((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4;   // q odd
   int a_ord = 0, a_kt = 0, a_seg = 0, a_off = 0;
-  Seg3 aseg = load_seg3(segtab, 0);
-  int gb[4], gy[4], gx[4]; bool gok[4]; long srow[4];
+  Seg3 aseg = load_seg3_uniform(segtab, 0);
+  int gb[4], gy[4], gx[4]; bool gok[4];
+  const unsigned char* ap[4];
+  auto a_ptrs = [&]() {
+    const int t = lw + a_ord * G;
+    const long m0 = (long)(t / ntn) * T3_BM;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long r = seg3_row(aseg, gok[q], gb[q], gy[q], gx[q], spatial, m0 + arow0 + 8 * q);
+      ap[q] = (r >= 0 ? aseg.p + ((r * aseg.ld) << 1) : zero) + ((q & 1) ? acb1 : acb0);
+    }
+  };
   auto a_tile_geo = [&]() {
     const int t = lw + a_ord * G;
     const long m0 = (long)(t / ntn) * T3_BM;
@@ -155,14 +183,8 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
         const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
         gb[q] = b; gy[q] = rem / g.a.Wo; gx[q] = rem - gy[q] * g.a.Wo;
       }
-      srow[q] = seg3_row(aseg, gok[q], gb[q], gy[q], gx[q], spatial, m);
     }
-  };
-  auto a_rows = [&]() {
-    const int t = lw + a_ord * G;
-    const long m0 = (long)(t / ntn) * T3_BM;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) srow[q] = seg3_row(aseg, gok[q], gb[q], gy[q], gx[q], spatial, m0 + arow0 + 8 * q);
+    a_ptrs();
   };
   a_tile_geo();
   auto issue_a = [&](int slot) {
@@ -170,18 +192,17 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
     if (a_ord < nt_my) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const unsigned char* src = zero;
-        if (srow[q] >= 0) src = aseg.p + ((srow[q] * aseg.ld + a_off) << 1) + ((q & 1) ? acb1 : acb0);
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dsm + dst + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)ap[q], (lds_void*)(dsm + dst + q * 1024), 16, 0, 0);
+        ap[q] += 2 * T3_BK;
       }
       a_off += T3_BK; ++a_kt;
       if (a_kt == nk) {
         ++a_ord; a_kt = 0; a_seg = 0; a_off = 0;
-        if (a_ord < nt_my) { aseg = load_seg3(segtab, 0); a_tile_geo(); }
+        if (a_ord < nt_my) { aseg = load_seg3_uniform(segtab, 0); a_tile_geo(); }
       } else if (a_off >= aseg.klen) {
         a_off = 0; ++a_seg;
-        aseg = load_seg3(segtab, a_seg);
-        a_rows();
+        aseg = load_seg3_uniform(segtab, a_seg);
+        a_ptrs();
       }
     } else {
 #pragma unroll
@@ -192,24 +213,30 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
 
   // ---- W issue state: 3 wave-instructions per wave and stage (rows 8 (3 wid + q) + (lane >> 3))
   int b_ord = 0, b_kt = 0;
-  int wrow[3], wcb[3];
+  const unsigned char* wp[3];
+  auto b_ptrs = [&]() {
+    const int t = lw + b_ord * G;
+    const int n0 = (t % ntn) * T3_BN;
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int row = 8 * (3 * wid + q) + (lane >> 3);
-    const int f = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
-    wrow[q] = row; wcb[q] = ((lane & 7) ^ f) << 4;
-  }
+    for (int q = 0; q < 3; ++q) {
+      const int row = 8 * (3 * wid + q) + (lane >> 3);
+      const int f = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
+      wp[q] = (const unsigned char*)g.W + (((long)(n0 + row) * g.ldw) << 1) + (((lane & 7) ^ f) << 4);
+    }
+  };
+  b_ptrs();
   auto issue_b = [&](int slot) {
     const uint32_t dst = T3_BOFF + T3_BST * slot + wid * 3072;
     if (b_ord < nt_my) {
-      const int t = lw + b_ord * G;
-      const int n0 = (t % ntn) * T3_BN;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const unsigned char* src = (const unsigned char*)g.W + (((long)(n0 + wrow[q]) * g.ldw + (long)b_kt * T3_BK) << 1) + wcb[q];
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dsm + dst + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)wp[q], (lds_void*)(dsm + dst + q * 1024), 16, 0, 0);
+        wp[q] += 2 * T3_BK;
       }
-      if (++b_kt == nk) { b_kt = 0; ++b_ord; }
+      if (++b_kt == nk) {
+        b_kt = 0; ++b_ord;
+        if (b_ord < nt_my) b_ptrs();
+      }
     } else {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
@@ -1027,7 +1054,7 @@ bool sodt_nt3_eligible(const sodt_gemm_args* g) {
   if ((g->flags & SODT_EPI_BIAS) && g->N > T3_MAXBIAS) return false;
   if ((g->ldw % 8) || (g->ldc % 8)) return false;
   for (int i = 0; i < g->a.nseg; ++i)
-    if (g->a.s[i].klen % T3_BK) return false;
+    if (g->a.s[i].klen % T3_BK || g->a.s[i].klen > T3_MAXKLEN) return false;
   return true;
 }
 
