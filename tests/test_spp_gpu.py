@@ -48,6 +48,40 @@ def test_maxpool5_cascade_matches_torch_5_9_13(ops, dev, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_maxpool_cascade_backward_with_exact_ties(ops, dev, dt):
+    """The WHOLE pooling backward of SPP as the engine runs it (d m13 -> m9 -> m5 -> input, each stage accumulating into the slice
+    below: engine._spp_bwd, spp.SPPOp.backward) on a map full of exact ties, in both dtypes, against autograd through the same
+    cascade of three MaxPool2d(5, 1, 2): first-maximum routing at every stage makes the two agree ELEMENTWISE (values are small
+    integers / halves: exact in f32, and in bf16 up to the rounding of the few sums above 256), so a dropped pool or a mis-routed slice cannot hide behind "tie routing" (advisor r3)."""
+    B, C, H, W = 2, 16, 11, 12
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5).round() / 2
+    x[:, :, 3:8, 2:9] = 1.0                                                   # a constant plateau: every window inside it ties
+    xr = x.clone().requires_grad_(True)
+    p5 = F.max_pool2d(xr, 5, 1, 2); p9 = F.max_pool2d(p5, 5, 1, 2); p13 = F.max_pool2d(p9, 5, 1, 2)
+    dys = [torch.randint(-3, 4, (B, C, H, W), generator=g).float() for _ in range(4)]      # d(cat slices): a1, m5, m9, m13
+    (xr * dys[0] + p5 * dys[1] + p9 * dys[2] + p13 * dys[3]).sum().backward()
+    M = B * H * W
+    cat = torch.zeros(M, 4 * C, device=dev, dtype=dt)
+    cat[:, :C] = _tok(x).to(dev).to(dt)
+    arg = torch.zeros(3, M, C, device=dev, dtype=torch.uint8)
+    for i in range(3):
+        ops.maxpool5_fwd(cat, cat, arg[i], B, H, W, C, ldx=4 * C, ldy=4 * C, x_off=i * C, y_off=(i + 1) * C)
+    for i, r in enumerate((p5, p9, p13)):
+        assert torch.equal(_nchw(cat[:, (i + 1) * C:(i + 2) * C].float().cpu(), B, H, W), r.detach())
+    dcat = torch.cat([_tok(d) for d in dys], 1).to(dev).to(dt).contiguous()
+    for i in (2, 1, 0):
+        ops.maxpool5_bwd(dcat, arg[i], dcat, B, H, W, C, lddy=4 * C, lddx=4 * C, dy_off=(i + 1) * C, dx_off=i * C, accumulate=True)
+    torch.cuda.synchronize()
+    got = _nchw(dcat[:, :C].float().cpu(), B, H, W)
+    if dt == torch.float32:
+        assert torch.equal(got, xr.grad)
+    else:       # integer sums above 256 round in bf16 (three accumulating stages): one part in 64 of the largest element
+        assert float((got - xr.grad).abs().max()) <= float(xr.grad.abs().max()) / 64
+        assert float(((got - xr.grad).abs() > 0).float().mean()) <= 0.02          # and only the few large sums are touched at all
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_spp_operator_vs_reference_golden(dev, dt):
     S = importlib.import_module(PKG + ".spp")
     g = torch.load(os.path.join(GOLD, "spp.pt"))
