@@ -138,8 +138,8 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   __syncthreads();
   const uint32_t segtab = lbase + T3_SEGOFF;
 
-  const int ntn = g.N / T3_BN;
-  const int ntm = (g.M + T3_BM - 1) / T3_BM;
+  const int ntn = (g.N + T3_BN - 1) / T3_BN;          // N % 8 == 0; the last column tile may be partial (rows >= N of W read as zeros,
+  const int ntm = (g.M + T3_BM - 1) / T3_BM;          //  their output chunks not stored)
   const int ntiles = ntm * ntn;
   const int G = gridDim.x;
   const int lw = xcd_remap(blockIdx.x, G);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
     for (int q = 0; q < 3; ++q) {
       const int row = 8 * (3 * wid + q) + (lane >> 3);
       const int f = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
-      wp[q] = (const unsigned char*)g.W + (((long)(n0 + row) * g.ldw) << 1) + (((lane & 7) ^ f) << 4);
+      wp[q] = (n0 + row < g.N ? (const unsigned char*)g.W + (((long)(n0 + row) * g.ldw) << 1) : zero) + (((lane & 7) ^ f) << 4);
     }
   };
   b_ptrs();
@@ -267,7 +267,8 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   // epilogue operand (residual / GELU input) of the tile being finished: fetched with inline-asm loads at the START of
   // the tile's last K-step, ahead of that step's DMA issues, so it lands under the MFMAs and is waited for with a
   // counted vmcnt(7); a compiler-visible load in the epilogue would wait vmcnt(0) and drain the DMA queue every tile
-  constexpr bool PRE = (CF & (SODT_EPI_RESID | SODT_EPI_DGELU)) != 0;
+  constexpr bool PRE = (CF & (SODT_EPI_RESID | SODT_EPI_DGELU | SODT_EPI_DRELU)) != 0;
+  static_assert(!((CF & SODT_EPI_RESID) && (CF & (SODT_EPI_DGELU | SODT_EPI_DRELU))), "one prefetched epilogue operand");
   // SODT_EPI_DGELU_RC: at the middle of the K range the accumulators hold the recomputed pre-activation; gelu'(h) is
   // parked (bf16) in the same registers the prefetched operand would use and the accumulators restart for dh_act
   constexpr bool RC = (CF & SODT_EPI_DGELU_RC) != 0;
@@ -288,7 +289,9 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
         if (m >= g.M) m = g.M - 1;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          const bf16* ptr = base + m * ldp + n0 + wc * 96 + 32 * t + 8 * fg;
+          int n = n0 + wc * 96 + 32 * t + 8 * fg;
+          if (n >= g.N) n = 0;                                  // (partial column tile: any in-bounds address, the chunk is not stored)
+          const bf16* ptr = base + m * ldp + n;
           asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre[u][t]) : "v"(ptr) : "memory");
         }
       }
@@ -370,7 +373,8 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               if (RC) v[j] *= x[j];                               // parked gelu'(h)
-              else if (CF & SODT_EPI_DGELU) v[j] *= dgelu_t<bf16>(x[j]);     // same order as epi_chunk: (bias, dgelu, resid)
+              else if (CF & SODT_EPI_DGELU) v[j] *= dgelu_t<bf16>(x[j]);     // same order as epi_chunk: (bias, dgelu | drelu, resid)
+              else if (CF & SODT_EPI_DRELU) v[j] = x[j] > 0.f ? v[j] : 0.f;
               else v[j] += x[j];
             }
           }
@@ -380,8 +384,8 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
             v[0] += __uint_as_float(b0.x); v[1] += __uint_as_float(b0.y); v[2] += __uint_as_float(b0.z); v[3] += __uint_as_float(b0.w);
             v[4] += __uint_as_float(b1.x); v[5] += __uint_as_float(b1.y); v[6] += __uint_as_float(b1.z); v[7] += __uint_as_float(b1.w);
           }
-          constexpr int CF2 = CF & ~(SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_DGELU | SODT_EPI_DGELU_RC);
-          if (m < g.M) {
+          constexpr int CF2 = CF & ~(SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_DGELU | SODT_EPI_DGELU_RC | SODT_EPI_DRELU);
+          if (m < g.M && n < g.N) {
             if constexpr (OSC) epi_chunk<bf16, -1>(g, CF2, m, n, v, hw);      // (generic path: knows the row scatter)
             else epi_chunk<bf16, CF2>(g, CF2, m, n, v, hw);
           }
@@ -404,7 +408,7 @@ int launch_nt3(const sodt_gemm_args* g, hipStream_t st) {
     }
     attr_set = true;
   }
-  const long ntiles = (long)((g->M + T3_BM - 1) / T3_BM) * (g->N / T3_BN);
+  const long ntiles = (long)((g->M + T3_BM - 1) / T3_BM) * ((g->N + T3_BN - 1) / T3_BN);
   const int grid = (int)(ntiles < 256 ? ntiles : 256);
   hipLaunchKernelGGL((gemm_nt3_kernel<CF, OSC>), dim3(grid), dim3(512), T3_LDS, st, *g);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
@@ -1042,15 +1046,19 @@ bool sodt_nt3_eligible(const sodt_gemm_args* g) {
   switch (g->flags) {
     case 0: case SODT_EPI_BIAS: case SODT_EPI_RESID: case SODT_EPI_BIAS | SODT_EPI_RESID:
     case SODT_EPI_BIAS | SODT_EPI_GELU_DUAL: case SODT_EPI_DGELU: case SODT_EPI_BIAS | SODT_EPI_GELU: break;
+    case SODT_EPI_RELU: case SODT_EPI_BIAS | SODT_EPI_RELU: case SODT_EPI_DRELU: break;      // the SR branch's convolutions (sr.py)
     case SODT_EPI_BIAS | SODT_EPI_DGELU_RC:
       if (g->K % (2 * T3_BK)) return false;        // both halves whole K-steps
       break;
     default: return false;
   }
   if (g->rmod > 0 || (g->oscatter && (g->flags != 0 || !g->a.spatial))) return false;
-  if (g->N % T3_BN || g->K % T3_BK || g->K < 192 || g->M < T3_BM) return false;
+  // N: whole 192-column tiles, or (K >= 512) any multiple of 8 with the last tile partial - a narrow output (the 64-channel 3x3
+  // convolutions of the SR branch, the 256-wide ones of its tail) is priced by the A stream, which this kernel moves by LDS-DMA
+  // three stages ahead; the idle accumulator columns cost matrix cycles that are not the bound there
+  if (g->N % 8 || (g->N % T3_BN && (g->K < 512 || g->K > T3_MAXKLEN)) || g->K % T3_BK || g->K < 192 || g->M < T3_BM) return false;
   if ((g->flags & SODT_EPI_RESID) && (g->ldr % 8)) return false;
-  if ((g->flags & SODT_EPI_DGELU) && (g->ldaux % 8)) return false;
+  if ((g->flags & (SODT_EPI_DGELU | SODT_EPI_DRELU)) && (g->ldaux % 8)) return false;
   if ((g->flags & SODT_EPI_BIAS) && g->N > T3_MAXBIAS) return false;
   if ((g->ldw % 8) || (g->ldc % 8)) return false;
   for (int i = 0; i < g->a.nseg; ++i)
@@ -1067,6 +1075,9 @@ int sodt_nt3_launch(const sodt_gemm_args* g, hipStream_t st) {
     case SODT_EPI_BIAS | SODT_EPI_GELU_DUAL: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_GELU_DUAL>(g, st);
     case SODT_EPI_DGELU: return launch_nt3<SODT_EPI_DGELU>(g, st);
     case SODT_EPI_BIAS | SODT_EPI_GELU: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_GELU>(g, st);
+    case SODT_EPI_RELU: return launch_nt3<SODT_EPI_RELU>(g, st);
+    case SODT_EPI_BIAS | SODT_EPI_RELU: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_RELU>(g, st);
+    case SODT_EPI_DRELU: return launch_nt3<SODT_EPI_DRELU>(g, st);
     case SODT_EPI_BIAS | SODT_EPI_DGELU_RC: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_DGELU_RC>(g, st);
     default: return SODT_EINVAL;
   }

@@ -95,29 +95,39 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const T* __restri
   }
 }
 
-// PixelShuffle(2): one thread = KPL consecutive OUTPUT channels of one output pixel (their sources are 4 channels apart)
+// PixelShuffle(2): out[b][2y + i][2x + j][c] = in[b][y][x][4c + 2i + j].  One thread = one 16-byte chunk of the SMALL-grid tensor
+// (KPL channels 4c + s = KPL / 4 output channels for each of the four sub-pixels): the wide side moves as 16-byte vectors, the
+// shuffled side as KPL / 4-element pieces that are contiguous ACROSS the threads of a wave (thread q + 1 holds the next output
+// channels of the same four pixels), so both sides are whole cache lines per wave.  (The first cut gathered 2-byte elements 8 bytes
+// apart on the small-grid side: 20 ms of the 252 ms SR step at B=4 @ 2048^2, profiles/r04_sr_step_kernel_stats.md.)
 template <typename T>
 __global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C,
                                                             int inverse) {
-  constexpr int KPL = TT<T>::KPL;
-  const int CH = C / KPL, Ho = 2 * H, Wo = 2 * W;
-  const long total = (long)B * Ho * Wo * CH;
+  constexpr int KPL = TT<T>::KPL, OC = KPL / 4;          // output channels per thread and sub-pixel: 2 (bf16) or 1 (f32)
+  const int CH = 4 * C / KPL, Wo = 2 * W;
+  const long total = (long)B * H * W * CH;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long m = i / CH; const int c0 = (int)(i - m * CH) * KPL;
-    const int b = (int)(m / ((long)Ho * Wo)); const int rem = (int)(m - (long)b * Ho * Wo);
-    const int oy = rem / Wo, ox = rem - oy * Wo;
-    const long sm = ((long)b * H + (oy >> 1)) * W + (ox >> 1);
-    const int sub = 2 * (oy & 1) + (ox & 1);
+    const long m = i / CH; const int q = (int)(i - m * CH);
+    const int b = (int)(m / ((long)H * W)); const int rem = (int)(m - (long)b * H * W);
+    const int y = rem / W, x = rem - y * W;
+    const long o00 = ((long)(b * 2 * H + 2 * y) * Wo + 2 * x) * C + q * OC;       // in the (B, 2H, 2W, C) tensor
+    T v[KPL];
     if (!inverse) {
-      T v[KPL];
+      *(uint4*)v = *(const uint4*)(in + m * 4 * C + q * KPL);
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) v[j] = in[sm * 4 * C + 4 * (c0 + j) + sub];
-      *(uint4*)(out + m * C + c0) = *(const uint4*)v;
-    } else {
-      T v[KPL];
-      *(uint4*)v = *(const uint4*)(in + m * C + c0);   // `in` is the large side here
+      for (int s2 = 0; s2 < 4; ++s2) {
+        T* dst = out + o00 + ((long)(s2 >> 1) * Wo + (s2 & 1)) * C;
 #pragma unroll
-      for (int j = 0; j < KPL; ++j) out[sm * 4 * C + 4 * (c0 + j) + sub] = v[j];
+        for (int cc = 0; cc < OC; ++cc) dst[cc] = v[4 * cc + s2];
+      }
+    } else {                                             // `in` is the large side here
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const T* src = in + o00 + ((long)(s2 >> 1) * Wo + (s2 & 1)) * C;
+#pragma unroll
+        for (int cc = 0; cc < OC; ++cc) v[4 * cc + s2] = src[cc];
+      }
+      *(uint4*)(out + m * 4 * C + q * KPL) = *(const uint4*)v;
     }
   }
 }
@@ -187,7 +197,7 @@ extern "C" int sodt_bilinear_up2_bwd(const void* dy, int lddy, void* dx, const v
 
 extern "C" int sodt_pixel_shuffle2(const void* in, void* out, int B, int H, int W, int C, int inverse, int dtype, sodt_stream_t st) {
   if (!sr_ok(in, out, B, H, W, C, dtype)) return SODT_EINVAL;
-  const long n = (long)B * 4 * H * W * (C / (dtype == SODT_BF16 ? 8 : 4));
+  const long n = (long)B * H * W * (4 * C / (dtype == SODT_BF16 ? 8 : 4));
   if (dtype == SODT_BF16) hipLaunchKernelGGL(pixel_shuffle2_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)st, (const bf16*)in, (bf16*)out, B, H, W, C, inverse);
   else if (dtype == SODT_F32) hipLaunchKernelGGL(pixel_shuffle2_kernel<float>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)st, (const float*)in, (float*)out, B, H, W, C, inverse);
   else return SODT_EINVAL;

@@ -96,7 +96,7 @@ class _Conv:
     """GEMM views of one Conv2d: w [Np][taps*Cin] (forward), wT [Cin][taps*Np] (input gradient) in the run dtype; Np = Cout rounded
     up to 8 (zero rows / columns: the closing 64 -> ch convolution has 3 or 4 outputs).  The forward GEMM runs at N = Cout over the
     padded rows, as Detect's does (engine.py: det_np)."""
-    __slots__ = ("name", "cout", "cin", "k", "taps", "np_", "w", "wT", "bias")
+    __slots__ = ("name", "cout", "cin", "k", "taps", "np_", "w", "wT", "bias", "dw_pad", "db_pad")
 
 
 class SRBranch:
@@ -123,6 +123,10 @@ class SRBranch:
             c.taps = c.k * c.k
             c.np_ = (c.cout + 7) // 8 * 8
             c.bias = params.get(c.name + ".bias")
+            # Cout % 8 != 0: the weight gradient goes through an [Np][K] scratch (8-column dY: the pipelined TN kernel takes it;
+            # the narrow-N fallback kernel needed 14.6 ms per launch at 67 M rows) and its first Cout rows are added to .grad
+            c.dw_pad = torch.zeros(c.np_, c.cin * c.taps, device=self.dev) if c.np_ != c.cout else None
+            c.db_pad = torch.zeros(c.np_, device=self.dev) if (c.np_ != c.cout and c.bias is not None) else None
             if c.taps == 1 and c.np_ == c.cout and dt == torch.float32:
                 c.w = v.detach().view(c.cout, c.cin)
             else:
@@ -180,9 +184,23 @@ class SRBranch:
         dy: [M][lddy] with the gradient in the first Cout columns and zeros up to Np."""
         c = self.c[name]
         segs, sp = fwd
-        if wgrad:
+        if wgrad and c.dw_pad is None:
             ops.gemm_tn(dy, segs, self.g[name + ".weight"].view(c.cout, -1), M, c.cout, c.taps * c.cin, ldy=lddy, spatial=sp,
                         dbias=self.g[name + ".bias"] if c.bias is not None else None, kperm=(c.cin, c.taps) if c.k > 1 else None)
+        elif wgrad:
+            gw = self.g[name + ".weight"]
+            ops.zero_(c.dw_pad)
+            if c.db_pad is not None:
+                ops.zero_(c.db_pad)
+            ops.gemm_tn(dy, segs, c.dw_pad, M, c.np_, c.taps * c.cin, ldy=lddy, spatial=sp, dbias=c.db_pad,
+                        kperm=(c.cin, c.taps) if c.k > 1 else None)
+            ops.add_rows(gw.view(1, -1), c.dw_pad.view(1, -1), 1, gw.numel(), lds=gw.numel())
+            if c.db_pad is not None:
+                gb = self.g[name + ".bias"]
+                if c.cout % 4 == 0:
+                    ops.add_rows(gb.view(1, -1), c.db_pad.view(1, -1), 1, c.cout, lds=c.cout)
+                else:
+                    gb.add_(c.db_pad[: c.cout])          # (3 floats, ch = 3: below the 16-byte granule of the kernels)
         if dx is None:
             return
         n = c.cin if dx_n is None else dx_n

@@ -115,6 +115,40 @@ def _nhwc(x):   # (B,C,H,W) -> token-major (B*H*W, C)
     return x.permute(0, 2, 3, 1).reshape(B * H * W, Cc).contiguous()
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N", [64, 256, 320])
+def test_gemm_nt_relu_epilogues_and_partial_column_tiles(ops, dev, dt, N):
+    """SODT_EPI_RELU / SODT_EPI_DRELU (the SR branch's convolutions, sr.py) and, in bf16 with K >= 512, the pipelined kernel on an N
+    that is not a multiple of its 192-column tile (rows >= N of W come from the zero page, their chunks are not stored): 3x3 taps
+    over a (2, 24, 20, 64) image (K = 576), a row tail (M = 960), more column tiles than one when N = 256 / 320; the output buffer is
+    wider than N and its other columns must stay untouched."""
+    B, H, Wd, Cc = 2, 24, 20, 64
+    M, K = B * H * Wd, 9 * Cc
+    x = rnd((B, Cc, H, Wd), dev, dt, 1)
+    w4 = rnd((N, Cc, 3, 3), dev, dt, 2, 1 / math.sqrt(K))
+    Wg = w4.permute(0, 2, 3, 1).reshape(N, K).contiguous()                 # [n][tap * Cin + c]
+    bias = rnd((N,), dev, torch.float32, 3)
+    xt = _nhwc(x)
+    segs = [ops.SegSpec(xt, Cc, 0, dy, dx, 1, 0, H, Wd) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    ref = _nhwc(F.conv2d(x.float(), w4.float(), None, padding=1))
+    ld = N + 16
+    for mode in ("relu", "bias_relu", "drelu", "bias_resid"):
+        out = torch.full((M, ld), 7.0, device=dev, dtype=dt)
+        aux = rnd((M, N + 8), dev, dt, 5)                                  # (its own leading dimension and a column offset)
+        kw = dict(spatial=(H, Wd), ldc=ld, c_off=8)
+        if mode == "relu":
+            ops.gemm_nt(segs, Wg, out, M, N, K, relu=True, **kw); want = F.relu(ref)
+        elif mode == "bias_relu":
+            ops.gemm_nt(segs, Wg, out, M, N, K, bias=bias, relu=True, **kw); want = F.relu(ref + bias)
+        elif mode == "drelu":
+            ops.gemm_nt(segs, Wg, out, M, N, K, drelu_aux=aux, aux_off=8, **kw); want = ref * (aux[:, 8:].float() > 0)
+        else:
+            ops.gemm_nt(segs, Wg, out, M, N, K, bias=bias, resid=aux, ldr=N + 8, r_off=8, **kw); want = ref + bias + aux[:, 8:].float()
+        torch.cuda.synchronize()
+        close(out[:, 8:8 + N], want, dt, what=f"{mode} N={N}")
+        assert bool((out[:, :8] == 7.0).all()) and bool((out[:, 8 + N:] == 7.0).all()), f"{mode}: columns outside [8, 8 + N) were written"
+
+
 def test_gemm_nt_pipelined_bf16(ops, dev):
     """The LDS-DMA pipelined bf16 kernel (csrc/gemm3.hip: N % 192 == 0, K >= 384): every epilogue it is built
     for, a row tail, more tiles than workgroups (persistent walk), multi-segment and conv-tap A operands."""
