@@ -96,7 +96,7 @@ class _Conv:
     """GEMM views of one Conv2d: w [Np][taps*Cin] (forward), wT [Cin][taps*Np] (input gradient) in the run dtype; Np = Cout rounded
     up to 8 (zero rows / columns: the closing 64 -> ch convolution has 3 or 4 outputs).  The forward GEMM runs at N = Cout over the
     padded rows, as Detect's does (engine.py: det_np)."""
-    __slots__ = ("name", "cout", "cin", "k", "taps", "np_", "w", "wT", "bias", "dw_pad", "db_pad")
+    __slots__ = ("name", "cout", "cin", "k", "taps", "np_", "w", "wT", "bias", "dw_pad", "db_pad", "bias_pad")
 
 
 class SRBranch:
@@ -127,6 +127,9 @@ class SRBranch:
             # the narrow-N fallback kernel needed 14.6 ms per launch at 67 M rows) and its first Cout rows are added to .grad
             c.dw_pad = torch.zeros(c.np_, c.cin * c.taps, device=self.dev) if c.np_ != c.cout else None
             c.db_pad = torch.zeros(c.np_, device=self.dev) if (c.np_ != c.cout and c.bias is not None) else None
+            # ... and the forward runs at N = Np over the zero rows of w with a zero-padded bias copy (bf16: the pipelined kernel
+            # needs N % 8 == 0; the 128x128 K-loop kernel took 21.8 ms for the closing 64 -> 4 convolution at 67 M rows)
+            c.bias_pad = torch.zeros(c.np_, device=self.dev) if c.db_pad is not None else None
             if c.taps == 1 and c.np_ == c.cout and dt == torch.float32:
                 c.w = v.detach().view(c.cout, c.cin)
             else:
@@ -154,6 +157,9 @@ class SRBranch:
         """(Re-)lay the float32 masters out for the GEMMs (one launch); call after every optimizer step."""
         t, n, mx = self._tab
         ops.prep_weights(t, n, mx, L.BF16 if self.dt == torch.bfloat16 else L.F32)
+        for c in self.c.values():
+            if c.bias_pad is not None:
+                ops.cast(c.bias.detach(), c.bias_pad, c.cout)
 
     # ------------------------------------------------------------------ helpers
     def _buf(self, name, shape, dtype=None):
@@ -175,7 +181,9 @@ class SRBranch:
             assert s0.shr == 0 and s0.mul == 1
             segs = [SegSpec(s0.t, s0.klen, s0.coff, dy, dx, 1, 0, H, W, ld=s0.ld) for (dy, dx) in TAPS3]
             sp = (H, W)
-        ops.gemm_nt(segs, c.w, out, M, c.cout, c.taps * c.cin, spatial=sp, bias=c.bias, relu=relu, resid=resid, ldc=ldc, c_off=c_off)
+        padded = c.bias_pad is not None and ldc is None and out.shape[-1] == c.np_        # (the pad columns of `out` receive zeros)
+        ops.gemm_nt(segs, c.w, out, M, c.np_ if padded else c.cout, c.taps * c.cin, spatial=sp, bias=c.bias_pad if padded else c.bias,
+                    relu=relu, resid=resid, ldc=ldc, c_off=c_off)
         return segs, sp
 
     def _conv_bwd(self, name, dy, lddy, fwd, H, W, M, dx, *, dx_n=None, w_row0=0, drelu_aux=None, aux_off=0, resid=None, wgrad=True):
