@@ -2,10 +2,10 @@
 # Run on the GPU box (gpurun): HBM traffic and SQ / TCC counters of the pipelined bf16 NT GEMM at four bench shapes, one launch per
 # shape and process (tools/pmc_gemm.py); one --pmc group per pass, program directly after "--".   Usage: tools/pmc_gemm.sh <tag>
 TAG=${1:-r04}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcgemm_$TAG
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcgemm_${TAG}_${2:-pmc_gemm}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-P="python3 $GRAFT_REPO_ROOT/tools/pmc_gemm.py"
+P="python3 $GRAFT_REPO_ROOT/tools/${2:-pmc_gemm}.py"
 i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
