@@ -118,3 +118,32 @@ def test_sr_train_step_vs_oracle(dev, dtype, tol_out, tol_grad, which, monkeypat
     assert allr and allr[0][0] <= 1.0, f"worst gradient errors (error / bound, error, bound, name) {allr[:6]}"
     if which != "det_only":
         assert any(n.startswith("model_up.") for *_, n in allr)
+
+
+def test_sr_step_at_1024_bf16_and_property(dev):
+    """Size-independent property at full size (B = 2 @ 1024^2 bf16, output_sr (2, 4, 2048, 2048)): the SR branch has no cross-image
+    coupling (convolutions, ReLU, bilinear resize, PixelShuffle: all per image); with two IDENTICAL images in the batch the head's
+    BatchNorm statistics are those of one image, so image 1 must reproduce image 0 bit for bit; the step also runs twice on the
+    same plan (buffers reused, gradients accumulated into the flat buffer: the second backward doubles model_up's gradients)."""
+    from oracle import ref_torch as R
+    S = 1024
+    model, _ = build(dev, S)
+    model.compute_dtype = torch.bfloat16
+    model.train()
+    x_rgb, x_ir = R.synthetic_inputs(1, S, seed=4)
+    x_rgb, x_ir = x_rgb.repeat(2, 1, 1, 1).to(dev), x_ir.repeat(2, 1, 1, 1).to(dev)
+    pred, out_sr, _ = model(x_rgb, x_ir, "RGB+IR")
+    assert tuple(out_sr.shape) == (2, 4, 2 * S, 2 * S) and bool(torch.isfinite(out_sr).all())
+    assert torch.equal(out_sr[0], out_sr[1]), "two identical images of one batch give different SR outputs"
+    (out_sr.square().mean() + pred[0].float().square().mean()).backward()
+    g1 = {n: p.grad.clone() for n, p in model.named_parameters() if n.startswith("model_up.")}
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values()) and sum(float(v.abs().sum()) for v in g1.values()) > 0
+    enc = dict(model.named_parameters())["image_encoder.stage2.0.attn.qkv.weight"].grad
+    assert bool(torch.isfinite(enc).all()) and float(enc.abs().max()) > 0
+    pred, out_sr2, _ = model(x_rgb, x_ir, "RGB+IR")
+    # (BatchNorm column statistics are f64 atomic sums: their order may move a bf16 ulp between launches)
+    assert float((out_sr2 - out_sr).detach().abs().max()) <= 1e-2 * float(out_sr.detach().abs().max())
+    (out_sr2.square().mean() + pred[0].float().square().mean()).backward()
+    for n, p in model.named_parameters():
+        if n.startswith("model_up."):
+            assert float((p.grad - 2 * g1[n]).abs().max()) <= 2e-2 * (float(g1[n].abs().max()) + 1e-12), n
