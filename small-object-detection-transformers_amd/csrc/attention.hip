@@ -1117,7 +1117,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int hg = blockIdx.y, head = hg * NW + w;
+  // Workgroup -> (window walker bx of gxd, head group hg).  RC: a 1-D grid of 3 gxd workgroups, gxd % 8 == 0; the three head groups
+  // of a walker read the SAME xn1 rows, so they sit on one XCD (linear id % 8) at consecutive positions and the second and third
+  // read hit that XCD's L2 (with the (gx, 3) grid they sat 170 ids apart on other XCDs: pmc r04, 819 MB fetched for 427)
+  int bx, gxd, hg;
+  if constexpr (RC) {
+    const int id = blockIdx.x, k = id >> 3;
+    hg = k % 3; bx = (k / 3) * 8 + (id & 7); gxd = gridDim.x / 3;
+  } else { bx = blockIdx.x; gxd = gridDim.x; hg = blockIdx.y; }
+  const int head = hg * NW + w;
   const int C3 = 3 * g.C, L2 = 2 * g.ws - 1;
   const int R = 64 / g.ws, LT = (2 * R - 1) * L2;
   const float scale = rsqrtf((float)HD), scale2 = scale * SODT_LOG2E;
@@ -1222,9 +1230,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
     if constexpr (!RC) { *(uint4*)(sQ + off) = pq##i; *(uint4*)(sK + off) = pk##i; *(uint4*)(sV + off) = pv##i; } \
     *(uint4*)(sDO + off) = pd##i;                                                       \
   }
-  B2_ISSUE((int)blockIdx.x < nwin_total ? (int)blockIdx.x : 0)
+  B2_ISSUE(bx < nwin_total ? bx : 0)
 
-  for (int item = blockIdx.x; item < nwin_total; item += gridDim.x) {
+  for (int item = bx; item < nwin_total; item += gxd) {
     int t = item;
     const int wx = t % g.nwx; t /= g.nwx;
     const int wy = t % g.nwy; const int b = t / g.nwy;
@@ -1279,7 +1287,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
       __syncthreads();                                 // every wave is done with the xn1 tile: the dS patches may overwrite it
     }
     if constexpr (!LATE_PF) {
-      const int nxt = item + (int)gridDim.x < nwin_total ? item + (int)gridDim.x : item;
+      const int nxt = item + gxd < nwin_total ? item + gxd : item;
       B2_ISSUE(nxt)
     }
 
@@ -1390,7 +1398,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
     if constexpr (LATE_PF) {   // next window's Q / K / V / dO chunks + lse: issued after the strips so the 33 prefetch
         // registers are not live across the register-heaviest part of the kernel (234 VGPRs: two workgroups per CU, no
         // AGPR copies); they land under the staging / store phase and the other workgroup's compute
-      const int nxt = item + (int)gridDim.x < nwin_total ? item + (int)gridDim.x : item;
+      const int nxt = item + gxd < nwin_total ? item + gxd : item;
       B2_ISSUE(nxt)
     }
     // ---- stage dQ / dK / dV through this head's own Q / K / V tiles, then coalesced stores
@@ -1420,7 +1428,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
   __syncthreads();
   for (int i = tid; i < NW * (LTMAX + 3); i += NT) (&sDB[0][0])[i] = 0.f;
   __syncthreads();
-  if (nwin_total > (int)blockIdx.x) {
+  if (nwin_total > bx) {
 #pragma unroll
     for (int dc = 0; dc < 7; ++dc)
 #pragma unroll
@@ -2314,8 +2322,10 @@ int launch_bwd_rc(const void* xn1, const unsigned char* wpk, const float* bias_t
                   float* dbias_t, const AttnGeo& g, hipStream_t st) {
   if (g.heads != 12 || g.C != 192 || g.nqt != 1 || g.ws != 8) return SODT_EINVAL;
   const int nwin = g.B * g.nwy * g.nwx;
-  const int gx = bwd_persistent_grid(nwin, g.heads / 4, 4);
-  hipLaunchKernelGGL((attn_bwd_fast2_kernel<bf16, 16, 4, true, true>), dim3(gx, g.heads / 4), dim3(256), 0, st,
+  int gx = bwd_persistent_grid(nwin, g.heads / 4, 4);
+  gx = gx >= 8 ? gx / 8 * 8 : 8;                      // walkers in whole rounds of the 8 XCDs (see the kernel's id map); walkers
+  //                                                    beyond the window count only join the final (all-zero) bias-gradient flush
+  hipLaunchKernelGGL((attn_bwd_fast2_kernel<bf16, 16, 4, true, true>), dim3(3 * gx), dim3(256), 0, st,
                      (const bf16*)xn1, bias_t, (const bf16*)dout, lsew, (bf16*)dqkv, dbias_t, g, nwin, wpk);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
