@@ -39,10 +39,12 @@ __device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int rtf
       for (int j = 0; j < KPL; ++j) if (n + j < g.N) v[j] += g.bias[n + j];
     }
   }
+#ifndef SODT_EXP_NO_ACT          // (A/B builds of tools/exp/ab_build.sh only: what the activation's VALU work costs)
   if (flags & SODT_EPI_GELU) {
 #pragma unroll
     for (int j = 0; j < KPL; ++j) v[j] = gelu_t<T>(v[j]);
   }
+#endif
   if (flags & SODT_EPI_RELU) {
 #pragma unroll
     for (int j = 0; j < KPL; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -102,7 +104,12 @@ __device__ __forceinline__ void epi_chunk(const sodt_gemm_args& g, const int rtf
     for (int j = 0; j < KPL; ++j) if (full || n + j < g.N) cp[j] = v[j];
   } else {
     T* cp = (T*)g.C + orow * g.ldc + n;
+#ifdef SODT_EXP_NO_STORE         // (A/B builds only: what the output stores cost - one store per 256 rows keeps the work alive)
+    if (full && (m & 255) == 0) *(uint4*)cp = pack<T>(v);
+    else if (full) asm volatile("" :: "v"(pack<T>(v).x));
+#else
     if (full) *(uint4*)cp = pack<T>(v);
+#endif
     else for (int j = 0; j < KPL; ++j) if (n + j < g.N) cp[j] = from_f<T>(v[j]);
     if (flags & SODT_EPI_GELU_DUAL) {
       float a[KPL];
