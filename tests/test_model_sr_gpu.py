@@ -147,3 +147,46 @@ def test_sr_step_at_1024_bf16_and_property(dev):
     for n, p in model.named_parameters():
         if n.startswith("model_up."):
             assert float((p.grad - 2 * g1[n]).abs().max()) <= 2e-2 * (float(g1[n].abs().max()) + 1e-12), n
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_sr_training_loop_loss_falls(dev, dt):
+    """Train.py:405-453 in miniature WITH --super: forward, ComputeLoss + the SR L1 term of Train.py:426 (0.1 x (L1(output_sr[:, :3],
+    image) + L1(output_sr[:, 3:], ir[:, :1])) against the 2x bilinear upsample of the inputs), hand-written backward through both
+    branches, FusedSGD (the 82 model_up tensors live in the engine's flat buffers like every other parameter) + ModelEMA: both loss
+    terms fall on a fixed batch and the SR parameters move."""
+    PKG = "small-object-detection-transformers_amd"
+    O = importlib.import_module(PKG + ".optim")
+    LS = importlib.import_module(PKG + ".loss")
+    S, B = 128, 2
+    torch.manual_seed(0)
+    model, _ = build(dev, S)
+    M = importlib.import_module(PKG + ".sr")
+    fresh = M.DeepLab(4, 128, 512)                      # the reference's own initialisation (kaiming / Conv2d default) for the branch
+    model.model_up.load_state_dict(fresh.state_dict())
+    model.compute_dtype = dt
+    model.train()
+    model.hyp, model.gr, model.nc = dict(LS.DEFAULT_HYP), 1.0, 8
+    ema = O.ModelEMA(model)
+    opt = O.FusedSGD(O.set_weight_decay(model), model=model, lr=0.01, momentum=0.937, nesterov=True, ema=ema)
+    compute_loss = LS.ComputeLoss(model)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, 3, S, S, generator=g).to(dev)
+    ir = torch.rand(B, 3, S, S, generator=g).to(dev)
+    hr = torch.nn.functional.interpolate(torch.cat([x, ir[:, :1]], 1), scale_factor=2, mode="bilinear", align_corners=True)
+    targets = LS.synthetic_targets(B, 16, 8, seed=1).to(dev)
+    w0 = model.model_up.edsr.tail[1].weight.detach().clone()
+    det, srl = [], []
+    for _ in range(16):
+        pred, out_sr, _ = model(x, ir, "RGB+IR")
+        l_det = compute_loss(pred, targets)[0]
+        l_sr = 0.1 * ((out_sr[:, :3] - hr[:, :3]).abs().mean() + (out_sr[:, 3:] - hr[:, 3:]).abs().mean())
+        (l_det + l_sr * B).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        ema.update(model)
+        det.append(float(l_det.detach()) / B); srl.append(float(l_sr.detach()))
+    assert all(v == v for v in det + srl), (det, srl)
+    assert det[-1] < 0.9 * det[0], det
+    assert srl[-1] < 0.9 * srl[0], srl
+    assert float((model.model_up.edsr.tail[1].weight.detach() - w0).abs().max()) > 0
