@@ -113,7 +113,9 @@ __device__ __forceinline__ long seg3_row(const Seg3& s, bool ok, int b, int y, i
 
 // OSC: the output rows are scattered (PatchMerging backward: row m of the half-resolution grid -> one of the four
 // stride-2 positions of the full grid); only with CF == 0
-template <int CF, bool OSC = false>
+// NV < 3 ("thin" instantiations, N <= 32 NV, one column tile): only the waves wc = 0 hold real columns, in their first NV 32-column
+// groups - the other fragment reads and MFMAs do not exist in the instantiation (a run-time skip cost 31-397 spilled registers).
+template <int CF, bool OSC = false, int NV = 3>
 __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: LDS-DMA destinations stay in SGPRs)
@@ -293,6 +295,8 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   // SODT_EPI_DGELU_RC: at the middle of the K range the accumulators hold the recomputed pre-activation; gelu'(h) is
   // parked (bf16) in the same registers the prefetched operand would use and the accumulators restart for dh_act
   constexpr bool RC = (CF & SODT_EPI_DGELU_RC) != 0;
+  // (thin instantiations: t < NV only - an inline-asm load whose result the compiler can prove unused gets its destination
+  //  registers re-allocated while the load is still in flight)
   u32x4 pre[4][3];
   for (int s = 0; s < total; ++s) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // everything but the newest A stage has landed
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
         long m = m0 + wr * 64 + 16 * u + fi;
         if (m >= g.M) m = g.M - 1;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NV; ++t) {
           int n = n0 + wc * 96 + 32 * t + 8 * fg;
           if (n >= g.N) n = 0;                                  // (partial column tile: any in-bounds address, the chunk is not stored)
           const bf16* ptr = base + m * ldp + n;
@@ -343,10 +347,36 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
       mma_sw(acc[3][2][0], fw4, fa3); mma_sw(acc[3][2][1], fw5, fa3);                \
       T3_PRIO_LO();                                                                  \
     }
-    T3_KB(aRd0, wRd0)
-    if (PRE || RC) __builtin_amdgcn_sched_barrier(0);   // keep the second half's fragment reads behind the first half's MFMAs:
-    T3_KB(aRd1, wRd1)                             //  frees ~40 VGPRs for the prefetched epilogue operand (no spills)
+#define T3_KBP(ARD, WRD)                                                             \
+    {                                                                                \
+      u32x4 fa0 = lds_rd128<0>(ARD + ao), fa1 = lds_rd128<2048>(ARD + ao);            \
+      u32x4 fa2 = lds_rd128<4096>(ARD + ao), fa3 = lds_rd128<6144>(ARD + ao);         \
+      u32x4 fw0 = lds_rd128<0>(WRD + bo), fw1 = lds_rd128<512>(WRD + bo);             \
+      u32x4 fw2 = fw0, fw3 = fw1;                                                    \
+      if constexpr (NV > 1) { fw2 = lds_rd128<4096>(WRD + bo); fw3 = lds_rd128<4608>(WRD + bo); } \
+      T3_LGKM0();                                                                    \
+      mma_sw(acc[0][0][0], fw0, fa0); mma_sw(acc[0][0][1], fw1, fa0);                \
+      mma_sw(acc[1][0][0], fw0, fa1); mma_sw(acc[1][0][1], fw1, fa1);                \
+      mma_sw(acc[2][0][0], fw0, fa2); mma_sw(acc[2][0][1], fw1, fa2);                \
+      mma_sw(acc[3][0][0], fw0, fa3); mma_sw(acc[3][0][1], fw1, fa3);                \
+      if constexpr (NV > 1) {                                                        \
+        mma_sw(acc[0][1][0], fw2, fa0); mma_sw(acc[0][1][1], fw3, fa0);              \
+        mma_sw(acc[1][1][0], fw2, fa1); mma_sw(acc[1][1][1], fw3, fa1);              \
+        mma_sw(acc[2][1][0], fw2, fa2); mma_sw(acc[2][1][1], fw3, fa2);              \
+        mma_sw(acc[3][1][0], fw2, fa3); mma_sw(acc[3][1][1], fw3, fa3);              \
+      }                                                                              \
+    }
+    if constexpr (NV == 3) {
+      T3_KB(aRd0, wRd0)
+      if (PRE || RC) __builtin_amdgcn_sched_barrier(0);   // keep the second half's fragment reads behind the first half's MFMAs:
+      T3_KB(aRd1, wRd1)                             //  frees ~40 VGPRs for the prefetched epilogue operand (no spills)
+    } else if (wc == 0) {
+      T3_KBP(aRd0, wRd0)
+      __builtin_amdgcn_sched_barrier(0);
+      T3_KBP(aRd1, wRd1)
+    }
 #undef T3_KB
+#undef T3_KBP
     a_slot = a_slot == 2 ? 0 : a_slot + 1;
     b_slot ^= 1;
     if (RC && c_kt + 1 == (nk >> 1)) {
@@ -382,7 +412,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
       for (int u = 0; u < 4; ++u) {
         const long m = m0 + wr * 64 + 16 * u + fi;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NV; ++t) {
           float v[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) { v[r] = acc[u][t][0][r]; v[4 + r] = acc[u][t][1][r]; }
@@ -419,11 +449,11 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the dummy tail DMAs must land before the LDS is released
 }
 
-template <int CF, bool OSC = false>
+template <int CF, bool OSC = false, int NV = 3>
 int launch_nt3(const sodt_gemm_args* g, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_nt3_kernel<CF, OSC>, hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)gemm_nt3_kernel<CF, OSC, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS) != hipSuccess) {
       (void)hipGetLastError();
       return SODT_EINVAL;
     }
@@ -431,7 +461,7 @@ int launch_nt3(const sodt_gemm_args* g, hipStream_t st) {
   }
   const long ntiles = (long)((g->M + T3_BM - 1) / T3_BM) * ((g->N + T3_BN - 1) / T3_BN);
   const int grid = (int)(ntiles < 256 ? ntiles : 256);
-  hipLaunchKernelGGL((gemm_nt3_kernel<CF, OSC>), dim3(grid), dim3(512), T3_LDS, st, *g);
+  hipLaunchKernelGGL((gemm_nt3_kernel<CF, OSC, NV>), dim3(grid), dim3(512), T3_LDS, st, *g);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
@@ -1088,6 +1118,17 @@ bool sodt_nt3_eligible(const sodt_gemm_args* g) {
 }
 
 int sodt_nt3_launch(const sodt_gemm_args* g, hipStream_t st) {
+  if (g->N <= 64 && !g->oscatter) {          // thin output (the 64-channel 3x3 convolutions of the SR branch and the head): NV = 2
+    switch (g->flags) {
+      case 0: return launch_nt3<0, false, 2>(g, st);
+      case SODT_EPI_BIAS: return launch_nt3<SODT_EPI_BIAS, false, 2>(g, st);
+      case SODT_EPI_BIAS | SODT_EPI_RESID: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_RESID, false, 2>(g, st);
+      case SODT_EPI_RESID: return launch_nt3<SODT_EPI_RESID, false, 2>(g, st);
+      case SODT_EPI_BIAS | SODT_EPI_RELU: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_RELU, false, 2>(g, st);
+      case SODT_EPI_DRELU: return launch_nt3<SODT_EPI_DRELU, false, 2>(g, st);
+      default: break;
+    }
+  }
   switch (g->flags) {
     case 0: return g->oscatter ? launch_nt3<0, true>(g, st) : launch_nt3<0>(g, st);
     case SODT_EPI_BIAS: return launch_nt3<SODT_EPI_BIAS>(g, st);
