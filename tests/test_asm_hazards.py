@@ -70,3 +70,24 @@ def test_pipelined_nt_gemm_has_no_spills_and_no_touched_inflight_destinations(ge
                 assert not hit, f"{name}: `{l}` touches v{sorted(hit)} while a prefetch load is still writing it"
         checked += 1
     assert checked >= 6          # the RESID / DGELU / DRELU instantiations, full and thin
+
+
+def test_fused_block_kernel_spill_budget(tmp_path):
+    """csrc/wmsa_hg.hip reads LDS with inline-asm `ds_read` retired by counted `lgkmcnt` waits: a build that spills around them
+    computes garbage (36 spilled registers once broke the multi-iteration save form).  The shipped state is 0
+    scratch instructions in the inference instantiations and <= 4 (cold exact-softmax fallback) in the training ones."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / "wmsa_hg.s")
+    src = os.path.join(ROOT, "small-object-detection-transformers_amd", "csrc", "wmsa_hg.hip")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", "-Wno-unused-value",
+                        "-Wno-inline-asm", "-S", "--cuda-device-only", "-o", out, src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = open(out).read()
+    ks = list(re.finditer(r"^(_Z[^:\n]*wmsa_hg_kernelILb([01])ELb([01])E[^:\n]*):.*?s_endpgm", asm, re.S | re.M))
+    assert len(ks) == 4
+    for m in ks:
+        n = len(re.findall(r"scratch_", m.group(0)))
+        limit = 4 if m.group(2) == "1" else 0            # <SAVE, STAMP>: training builds may spill in the cold path only
+        assert n <= limit, f"wmsa_hg_kernel<{m.group(2)}, {m.group(3)}>: {n} scratch instructions (limit {limit})"
