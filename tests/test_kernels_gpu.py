@@ -116,7 +116,7 @@ def _nhwc(x):   # (B,C,H,W) -> token-major (B*H*W, C)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("N", [64, 256, 320])
+@pytest.mark.parametrize("N", [8, 40, 64, 256, 320])
 def test_gemm_nt_relu_epilogues_and_partial_column_tiles(ops, dev, dt, N):
     """SODT_EPI_RELU / SODT_EPI_DRELU (the SR branch's convolutions, sr.py) and, in bf16 with K >= 512, the pipelined kernel on an N
     that is not a multiple of its 192-column tile (rows >= N of W come from the zero page, their chunks are not stored): 3x3 taps
