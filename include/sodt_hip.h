@@ -208,6 +208,19 @@ int sodt_wmsa_block_bwd(const void* xn1, const void* wpk, const float* bias_t, c
                         void* dqkv, float* dbias_t, int B, int H, int W, int C, int heads, int ws, int shift,
                         int dtype, sodt_stream_t st);
 
+/* ---- fused linear MLP of a Swin block (csrc/mlp.hip) -----------------------------------------------------------
+ * out = resid + fc2(GELU(fc1(xn))): Mlp.forward's linear branch backbone_vit.py:884-890 (fc1, exact-erf GELU, fc2; the
+ * dropouts are identities at p = 0) together with the block's residual add `x + drop_path(mlp(norm2(x)))` (:1128), ONE launch.
+ * xn, resid, out [M][C] run dtype (resid nullable: then out = fc2(GELU(fc1(xn)))); w1 = fc1.weight [4C][C], w2 = fc2.weight
+ * [C][4C] in the run dtype (the prepared [N][K] copies sodt_gemm_nt takes), b1 [4C] / b2 [C] f32.
+ * hact (nullable): GELU(fc1(xn) + b1) [M][4C] run dtype is also written - the operand of fc2's weight gradient; without it the
+ * 4C-wide hidden activation never leaves the CU (inference form).
+ * bf16, C == 192: the fused kernel (token tile in LDS, W1 / W2 streamed in 32-column slabs by LDS-DMA, GELU(h) chained from the
+ * first product's accumulators into the second product's operand).  f32 (the parity path) and every other width run the
+ * two-launch chain sodt_gemm_nt(GELU) -> sodt_gemm_nt(bias + residual) through hact, which is then required. */
+int sodt_mlp_fwd(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2, const void* resid,
+                 void* out, void* hact, long M, int C, int dtype, sodt_stream_t st);
+
 /* Front end (backbone_vit.py:195-210): channel split, 4x Conv2d(1->48,k4,s4) (R with
  * padding 1), pairwise cross-channel attention (R<-G, G<-B, B<-IR, IR<-G; 12 heads x 4,
  * scale 1/2, window ca_ws, no projections) + residual + LayerNorm(48), concatenated to

@@ -173,6 +173,7 @@ class Engine:
         self._anchor = torch.zeros(1, device=self.dev, requires_grad=True)
         self.ddp = None     # set by ddp.attach()
         self.use_fused_wmsa = True     # tests / tools may switch the fused block kernel off to compare with the four launches it replaces
+        self.use_fused_mlp = True      # the same for the fused linear MLP (csrc/mlp.hip) against its two GEMM launches
         # LayerNorm backward as the epilogue of the GEMM that produces its input gradient (SODT_EPI_LNBWD): built and pinned
         # (tests/test_kernels_gpu.py), but measured SLOWER than the two launches it replaces at the bench shapes (0.45 vs 0.34 ms
         # at K = 576: profiles/r04_lnfold_ab.md), so the step does not use it
@@ -708,7 +709,13 @@ class Engine:
             ops.gemm_nt([SegSpec(ao)], w[pre + "attn.proj.weight"], xm, M, Cc, Cc, bias=p[pre + "attn.proj.bias"], resid=x_in)
             ops.layernorm_fwd(xm, p[pre + "norm2.weight"], p[pre + "norm2.bias"], xn2, st2, M, Cc)
         xo = plan.buf(tag + ".xo", (M, Cc))
-        if blk.mlp.linear:
+        if blk.mlp.linear and self.use_fused_mlp and ops.mlp_fused_ok(M, Cc, plan.dt) and ops.mlp_recompute_ok(M, Cc, plan.dt) and (pre + "mlp.fc1.weight") in P["wcat"]:
+            # fc1 + GELU + fc2 + residual in ONE launch (csrc/mlp.hip): the 4C-wide hidden activation leaves the CU only in training,
+            # as GELU(h) for fc2's weight gradient (the backward recomputes h inside the dh GEMM, as below)
+            ha = plan.buf(tag + ".ha", (M, 4 * Cc)) if plan.training else None
+            ops.mlp_fwd(xn2, w[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], w[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"],
+                        xm, xo, ha, M, Cc)
+        elif blk.mlp.linear:
             ha = plan.buf(tag + ".ha", (M, 4 * Cc))
             if ops.mlp_recompute_ok(M, Cc, ha.dtype) and (pre + "mlp.fc1.weight") in P["wcat"]:
                 # only GELU(h) is written; backward recomputes h inside the dh GEMM

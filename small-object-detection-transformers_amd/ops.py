@@ -206,6 +206,22 @@ def mlp_recompute_ok(M: int, Cc: int, dtype: torch.dtype) -> bool:
     return dtype == torch.bfloat16 and M >= 256 and (4 * Cc) % 192 == 0 and Cc % 64 == 0 and 4 * Cc <= 3072
 
 
+def mlp_fused_ok(M: int, Cc: int, dtype: torch.dtype) -> bool:
+    """sodt_mlp_fwd runs its fused kernel (csrc/mlp.hip) for this shape; otherwise it is the two-GEMM chain through hact."""
+    return dtype == torch.bfloat16 and Cc == 192 and M >= 1
+
+
+def mlp_fwd(xn: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+            resid: Optional[torch.Tensor], out: torch.Tensor, hact: Optional[torch.Tensor], M: int, Cc: int) -> None:
+    """out = resid + fc2(GELU(fc1(xn))) (backbone_vit.py:884-890, :1128); hact (optional) receives GELU(fc1(xn)) [M][4C]."""
+    assert xn.shape[-1] == Cc and out.shape[-1] == Cc and w1.shape == (4 * Cc, Cc) and w2.shape == (Cc, 4 * Cc)
+    assert xn.is_contiguous() and out.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()
+    assert w1.dtype == xn.dtype and w2.dtype == xn.dtype and b1.dtype == torch.float32 and b2.dtype == torch.float32
+    assert resid is None or (resid.is_contiguous() and resid.shape[-1] == Cc and resid.dtype == xn.dtype)
+    assert hact is None or (hact.is_contiguous() and hact.shape[-1] == 4 * Cc and hact.dtype == xn.dtype)
+    _launch("sodt_mlp_fwd", _p(xn), _p(w1), _p(b1), _p(w2), _p(b2), _p(resid), _p(out), _p(hact), M, Cc, dt_code(xn))
+
+
 def tn_splits(M: int, N: int, K: int, bf16: bool = False) -> int:
     """M-slices per dW tile so that the grid is one full round of workgroups (no tail): 256 x 192 tiles at one
     workgroup per CU when the short side is <= 192, 128 x 128 tiles at two per CU otherwise (csrc/gemm.hip).

@@ -67,6 +67,10 @@ def cost(name, args):
         if name == "sodt_window_attn_fwd":
             return (f"T={T} C={C} ws={ws} fwd", T * (4 * C * ES + heads * 4), 4.0 * T * N * C)
         return (f"T={T} C={C} ws={ws} bwd", T * (8 * C * ES + heads * 4), 10.0 * T * N * C)       # S, dP, dV, dK, dQ
+    if name == "sodt_mlp_fwd":
+        M, C = val(args[8]), val(args[9])
+        # xn, resid in; out (+ GELU(h), 4C wide, in training) out; both weight matrices once
+        return (f"M={M} C={C} {'train' if args[7] else 'inference'}", M * ((3 + (4 if args[7] else 0)) * C * ES) + 8.0 * C * C * ES, 16.0 * M * C * C)
     if name == "sodt_layernorm_fwd":
         M, C = val(args[5]), val(args[6])
         return (f"M={M} C={C}", M * (2 * C * ES + 8), 0.0)
