@@ -5,18 +5,35 @@ tag = sys.argv[1]
 src = f"gpurun_out/pmcmem_{tag}"
 val = collections.defaultdict(dict)
 dur = collections.defaultdict(list)
+# A pass directory can hold the SAME launch pair measured by more than one process (tools/pmc_mem.sh runs under a wrapper whose
+# child is profiled too: two <pid>_counter_collection.csv per pass).  Each file is a complete measurement of one launch per form:
+# they are AVERAGED, never added (round 4 added them and every absolute value in r04a / r04b_wmsa_mem_pmc.md came out doubled -
+# VERDICT r4 "What's weak" 3), and a file that disagrees with its sibling by more than 5 % on a counter fails the run.
+samples = collections.defaultdict(list)          # (form, counter) -> [(file, per-launch value: rows of one file summed over dispatch dims)]
 for f in sorted(glob.glob(f"{src}/p*/*/*counter_collection.csv")):
+    per_file = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         if "wmsa_hg_kernel" not in r["Kernel_Name"]:
             continue
         form = "training" if "<true" in r["Kernel_Name"] or "ILb1E" in r["Kernel_Name"] else "inference"
-        val[form][r["Counter_Name"]] = val[form].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        per_file[(form, r["Counter_Name"])] += float(r["Counter_Value"])
         dur[(form, f)] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    for k, v in per_file.items():
+        samples[k].append((f, v))
+nfiles = collections.Counter()
+for (form, name), vs in samples.items():
+    xs = [v for _, v in vs]
+    m = sum(xs) / len(xs)
+    if m > 1e4 and (max(xs) - min(xs)) > 0.05 * m and name.startswith(("SQ_INSTS", "TCC_REQ", "TCC_READ", "TCC_WRITE")):   # (counts, not stall cycles)
+        raise SystemExit(f"{name} ({form}) differs between the processes of one pass: {vs}")
+    val[form][name] = m
+    nfiles[len(xs)] += 1
 names = sorted({n for f in val.values() for n in f})
 d = {form: sorted(v for (fm, _), v in dur.items() if fm == form) for form in ("inference", "training")}
 out = [f"# Memory-path and issue counters of wmsa_hg_kernel at the bench shape (T = 524,288, C = 192, shift 2), {tag}\n",
        "`tools/pmc_mem.sh`: ONE inference-form and ONE training-form launch per process (`tools/pmc_one.py`), at most four counters of one",
-       "hardware block per `rocprofv3 --pmc` pass (SQ: eight), program directly after `--`.  Values are per launch, summed over the chip.",
+       "hardware block per `rocprofv3 --pmc` pass (SQ: eight), program directly after `--`.  Values are per launch, summed over the chip",
+       f"(mean over the {max(nfiles) if nfiles else 0} process(es) that measured each pass - never their sum).",
        "Launch time under the profiler (median over the passes): " +
        ", ".join(f"{k} {v[len(v) // 2] / 1e3:.0f} us" for k, v in d.items() if v) + ".\n",
        "| counter | inference | training |", "|---|---|---|"]
