@@ -152,7 +152,9 @@ int sodt_window_attn_bwd(const void* qkv, const float* bias_t, const void* out, 
  *   output of a ReLU ([B*H*W][C]) and dx is zeroed where it was not positive.
  * sodt_pixel_shuffle2: nn.PixelShuffle(2) (edsr.py:23): out[b][2y+i][2x+j][c] = in[b][y][x][4c + 2i + j], in [B][H][W][4C] ->
  *   out [B][2H][2W][C]; inverse != 0 runs the adjoint (= inverse permutation) out -> in.
- * sodt_add_rows: dst[m][dcol .. dcol + C) += src[m][scol .. scol + C) (gradient accumulation where a feature has two consumers).
+ * sodt_add_rows: dst[m][dcol .. dcol + C) += src[m][scol .. scol + C) (gradient accumulation where a feature has two consumers); C, the
+ *   leading dimensions and the column offsets are multiples of 16 bytes and both pointers 16-byte aligned - except ONE f32 row (M == 1)
+ *   of fewer than 64 elements, which may have any width (the bias gradient of the 3-channel closing convolution).
  * sodt_nchw_f32_from_rows / sodt_rows_from_nchw_f32: y (B, C, H, W) f32 <-> token-major rows [B*H*W][ld] run dtype (C <= ld, the
  *   pad columns are written as zeros): the branch's output / its incoming gradient at the model boundary. */
 int sodt_bilinear_up2_fwd(const void* x, void* y, int ldy, int B, int H, int W, int C, int dtype, sodt_stream_t st);

@@ -169,11 +169,19 @@ __global__ __launch_bounds__(256) void rows_from_nchw_kernel(const float* __rest
   }
 }
 
+__global__ void add_small_f32_kernel(float* dst, const float* src, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] += src[threadIdx.x];
+}
+
 }  // namespace
 
+// the kernels move 16-byte chunks (uint4): pointers - including column-slice pointers formed by the callers - must be 16-byte aligned
+static bool al16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+  return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
 static bool sr_ok(const void* a, const void* b, int B, int H, int W, int C, int dtype) {
   const int kpl = dtype == SODT_BF16 ? 8 : 4;
-  return a && b && B > 0 && H > 0 && W > 0 && C > 0 && (C % kpl) == 0 && (long)B * H * W * 4 < (1L << 31);
+  return a && b && al16(a, b) && B > 0 && H > 0 && W > 0 && C > 0 && (C % kpl) == 0 && (long)B * H * W * 4 < (1L << 31);
 }
 
 extern "C" int sodt_bilinear_up2_fwd(const void* x, void* y, int ldy, int B, int H, int W, int C, int dtype, sodt_stream_t st) {
@@ -187,7 +195,7 @@ extern "C" int sodt_bilinear_up2_fwd(const void* x, void* y, int ldy, int B, int
 
 extern "C" int sodt_bilinear_up2_bwd(const void* dy, int lddy, void* dx, const void* relu_out, int B, int H, int W, int C, int dtype,
                                      sodt_stream_t st) {
-  if (!sr_ok(dy, dx, B, H, W, C, dtype) || lddy < C || (lddy % (dtype == SODT_BF16 ? 8 : 4))) return SODT_EINVAL;
+  if (!sr_ok(dy, dx, B, H, W, C, dtype) || !al16(relu_out) || lddy < C || (lddy % (dtype == SODT_BF16 ? 8 : 4))) return SODT_EINVAL;
   const long n = (long)B * H * W * (C / (dtype == SODT_BF16 ? 8 : 4));
   if (dtype == SODT_BF16) hipLaunchKernelGGL(bilinear_up2_bwd_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)st, (const bf16*)dy, lddy, (bf16*)dx, (const bf16*)relu_out, B, H, W, C);
   else if (dtype == SODT_F32) hipLaunchKernelGGL(bilinear_up2_bwd_kernel<float>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)st, (const float*)dy, lddy, (float*)dx, (const float*)relu_out, B, H, W, C);
@@ -206,7 +214,12 @@ extern "C" int sodt_pixel_shuffle2(const void* in, void* out, int B, int H, int 
 
 extern "C" int sodt_add_rows(void* dst, int ldd, int dcol, const void* src, int lds_, int scol, long M, int C, int dtype, sodt_stream_t st) {
   const int kpl = dtype == SODT_BF16 ? 8 : 4;
-  if (!dst || !src || M <= 0 || C <= 0 || (C % kpl) || (ldd % kpl) || (lds_ % kpl) || (dcol % kpl) || (scol % kpl)) return SODT_EINVAL;
+  if (dst && src && dtype == SODT_F32 && M == 1 && C > 0 && C < 64 && (C % kpl)) {
+    // one short f32 row below the 16-byte granule (the bias gradient of a 3-channel convolution): element-wise
+    hipLaunchKernelGGL(add_small_f32_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, (float*)dst + dcol, (const float*)src + scol, C);
+    return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+  }
+  if (!dst || !src || !al16(dst, src) || M <= 0 || C <= 0 || (C % kpl) || (ldd % kpl) || (lds_ % kpl) || (dcol % kpl) || (scol % kpl)) return SODT_EINVAL;
   const long n = M * (C / kpl);
   if (dtype == SODT_BF16) hipLaunchKernelGGL(add_rows_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)st, (bf16*)dst, ldd, dcol, (const bf16*)src, lds_, scol, M, C);
   else if (dtype == SODT_F32) hipLaunchKernelGGL(add_rows_kernel<float>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)st, (float*)dst, ldd, dcol, (const float*)src, lds_, scol, M, C);

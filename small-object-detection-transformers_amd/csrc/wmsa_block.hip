@@ -703,7 +703,10 @@ extern "C" int sodt_wmsa_block_fwd(const void* x, const void* wpk, void* xm, voi
     // throughput path: four waves per window (wmsa_hg.hip).  The one-wave-per-window bf16 build below only runs as the
     // instrumented diagnostic build armed through sodt_debug_wmsa_stamps (an explicit API call, no environment switch).
     if (!g_wmsa_stamp_enable) return wmsa_hg_launch(a, save, st);
-    return launch_block<bf16, 4, 2, false, true>(a, st);      // (instrumented build: inference form only - its training form writes q / k / v)
+    // instrumented build: inference form only (its training form would write q / k / v).  A training call while the stamps are armed
+    // must not silently run the inference form - xn1, ao, the statistics and lsew would stay unwritten for the backward
+    if (save) return SODT_EINVAL;
+    return launch_block<bf16, 4, 2, false, true>(a, st);
   }
   if (dtype == SODT_F32) return save ? launch_block<float, 2, 1, true>(a, st) : launch_block<float, 2, 1, false>(a, st);
   return SODT_EINVAL;

@@ -17,6 +17,8 @@ import os
 import ctypes as C
 from typing import Dict, List, Optional, Tuple
 
+import warnings
+
 import torch
 
 from . import _lib as L
@@ -272,7 +274,16 @@ class Engine:
                     if vals[yi][1] == level and sum(c for _, c, _ in vals[yi][0]) == cn:
                         return yi
                 raise NotImplementedError(f"sr=True: no feature-list entry has {cn} channels on the stride-{4 << level} grid")
-            self.sr_taps = (first(mu.c1, 0), first(mu.c2, 1))
+            def fits(yi, cn, level):
+                return yi in vals and vals[yi][1] == level and sum(c for _, c, _ in vals[yi][0]) == cn
+            l1, l2 = getattr(self.model, "l1", None), getattr(self.model, "l2", None)
+            if fits(l1, mu.c1, 0) and fits(l2, mu.c2, 1):
+                self.sr_taps = (l1, l2)                      # the yaml's own taps (model.py:286: model_up(y[l1], y[l2])) are usable
+            else:
+                self.sr_taps = (first(mu.c1, 0), first(mu.c2, 1))
+                warnings.warn(f"sr=True: y[l1={l1}] / y[l2={l2}] of the yaml do not have {mu.c1} channels on the stride-4 grid / {mu.c2} on the "
+                              f"stride-8 grid that DeepLab(c1, c2) takes; tapping y[{self.sr_taps[0]}] / y[{self.sr_taps[1]}] instead "
+                              "(DESIGN.md section 4.3: graph parity unpinned)")
             self.sr_parts = (vals[self.sr_taps[0]][0], vals[self.sr_taps[1]][0])
 
     def _unit_out_name(self, u):
@@ -331,6 +342,7 @@ class Engine:
         self.flat_cast: Dict[torch.dtype, torch.Tensor] = {}     # run-dtype mirror of flat_param (bf16 path)
         self.param_cast_fresh = False     # True: flat_cast == cast(flat_param) (set by optim.FusedSGD.step, cleared by invalidate_params)
         self._cast_version = -1           # params_version() at the moment the mirror was last made fresh
+        self._param_epoch = 0             # bumped by every write params_version() cannot see (optim.FusedSGD.step, invalidate_params)
 
     def params_version(self) -> int:
         """Sum of the parameters' autograd version counters: every in-place write through the Parameter objects
@@ -342,12 +354,14 @@ class Engine:
         """optim.FusedSGD.step: the fused kernel has just written cast(flat_param) into the mirror."""
         self.param_cast_fresh = True
         self._cast_version = self.params_version()
+        self._param_epoch += 1
 
     def invalidate_params(self):
         """Tell the engine the f32 masters were changed by something other than optim.FusedSGD (load_state_dict, a torch
         optimizer, manual edits): the run-dtype mirror is re-cast at the next forward.  In-place writes through the
         Parameter objects are also detected by their version counters (params_version)."""
         self.param_cast_fresh = False
+        self._param_epoch += 1
 
     def _check_param_views(self):
         for n in self.grad_order:
@@ -964,8 +978,14 @@ class Engine:
             names = [n for n in self.params if n.startswith("model_up.")]
             br = plan.sr = SRBranch({n: self.params[n] for n in names}, plan.dt, {n: self.g[n] for n in names},
                                     dec="model_up.sr_decoder.", edsr="model_up.edsr.")
+            br._prep_version = (self.params_version(), self._param_epoch)
         else:
-            br.prepare()
+            # re-lay the 82 SR tensors out only when a parameter may have changed: in-place writes through the Parameter objects
+            # (version counters) or the fused optimizer / invalidate_params() (epoch) - not on every forward of an accumulation step
+            ver = (self.params_version(), self._param_epoch)
+            if getattr(br, "_prep_version", None) != ver:
+                br.prepare()
+                br._prep_version = ver
         def segs(parts, level):
             h = t >> level
             return [SegSpec(self._ref_buf(plan, ref), c, 0, 0, 0, 1, shr, h >> shr, h >> shr) for ref, c, shr in parts]

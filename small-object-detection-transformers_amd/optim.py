@@ -141,7 +141,7 @@ class FusedSGD(torch.optim.Optimizer):
         if cast is not None:
             eng.mark_cast_fresh()
         else:
-            eng.param_cast_fresh = False
+            eng.invalidate_params()         # (no mirror to keep fresh; the engine still has to know the masters moved: _param_epoch)
         return loss
 
     def state_dict(self):

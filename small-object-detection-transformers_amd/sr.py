@@ -205,10 +205,7 @@ class SRBranch:
             ops.add_rows(gw.view(1, -1), c.dw_pad.view(1, -1), 1, gw.numel(), lds=gw.numel())
             if c.db_pad is not None:
                 gb = self.g[name + ".bias"]
-                if c.cout % 4 == 0:
-                    ops.add_rows(gb.view(1, -1), c.db_pad.view(1, -1), 1, c.cout, lds=c.cout)
-                else:
-                    gb.add_(c.db_pad[: c.cout])          # (3 floats, ch = 3: below the 16-byte granule of the kernels)
+                ops.add_rows(gb.view(1, -1), c.db_pad.view(1, -1), 1, c.cout, lds=c.cout)      # (cout = 3: sodt_add_rows' short-row path)
         if dx is None:
             return
         n = c.cin if dx_n is None else dx_n
