@@ -223,6 +223,27 @@ int sodt_wmsa_block_bwd(const void* xn1, const void* wpk, const float* bias_t, c
 int sodt_mlp_fwd(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2, const void* resid,
                  void* out, void* hact, long M, int C, int dtype, sodt_stream_t st);
 
+/* ---- 2x2-conv MLP of the shifted Swin blocks with fc1 folded into the convolution (csrc/convmlp.hip), bf16 -------------------
+ * Mlp.forward's convolutional branch, backbone_vit.py:892-905: fc1 (C -> C), F.pad right / bottom, conv1 (2x2), GELU, fc2.  conv1 o fc1 is
+ * one linear map per tap, so the 2x2 convolution runs directly on the LayerNorm output with composed weights and bias; the tokens of
+ * the last column / row (where the padded fc1 output is zero including its bias) get a correction.  Exact algebra, bf16 rounding
+ * differs (fc1's output is never rounded).  f32 masters in their torch layouts: fc1_w [C][C], conv_w [C][C][2][2] (tap = kh * 2 + kw).
+ * sodt_convmlp_compose: weff bf16 [C][4C] (column tap * C + ci: the W operand of sodt_gemm_nt over the four tap segments), weffT bf16
+ *   [C][4C] (row ci, column tap * C + co: the W operand of the input-gradient GEMM over the negated taps), beff f32 [C] = conv bias +
+ *   sum_taps Wc_tap b1, vtap f32 [4][C] = Wc_tap b1.  Run once per forward (the masters change every step).
+ * sodt_convmlp_border_fix: cp (pre-activation) and ca (GELU of it) [B*H*W][C] as written by the GEMM with beff: on the tokens with
+ *   x == W - 1 / y == H - 1 the taps outside the image lose their vtap again and ca is recomputed.
+ * sodt_convmlp_border_sums: bs f32 [3][C] (zeroed by the caller) += sums of dc [B*H*W][C] over the last-column tokens, the last-row
+ *   tokens and the corner tokens.
+ * sodt_convmlp_decompose: parameter gradients by the chain rule from dweff f32 [C][4C] (= dc^T x(taps), sodt_gemm_tn without kperm),
+ *   colsum f32 [C] (its dbias) and bs: g_conv_w [C][C][2][2], g_conv_b, g_fc1_w, g_fc1_b are ADDED to. */
+int sodt_convmlp_compose(const float* fc1_w, const float* fc1_b, const float* conv_w, const float* conv_b, void* weff, void* weffT,
+                         float* beff, float* vtap, int C, int dtype, sodt_stream_t st);
+int sodt_convmlp_border_fix(void* cp, void* ca, const float* vtap, int B, int H, int W, int C, int dtype, sodt_stream_t st);
+int sodt_convmlp_border_sums(const void* dc, float* bs, int B, int H, int W, int C, int dtype, sodt_stream_t st);
+int sodt_convmlp_decompose(const float* dweff, const float* colsum, const float* bs, const float* fc1_w, const float* fc1_b,
+                           const float* conv_w, float* g_conv_w, float* g_conv_b, float* g_fc1_w, float* g_fc1_b, int C, sodt_stream_t st);
+
 /* Front end (backbone_vit.py:195-210): channel split, 4x Conv2d(1->48,k4,s4) (R with
  * padding 1), pairwise cross-channel attention (R<-G, G<-B, B<-IR, IR<-G; 12 heads x 4,
  * scale 1/2, window ca_ws, no projections) + residual + LayerNorm(48), concatenated to

@@ -123,6 +123,10 @@ SIGNATURES = {
     "sodt_add_rows": [_P, _I, _I, _P, _I, _I, _L, _I, _I, _P],
     "sodt_nchw_f32_from_rows": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "sodt_rows_from_nchw_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sodt_convmlp_compose": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "sodt_convmlp_border_fix": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sodt_convmlp_border_sums": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "sodt_convmlp_decompose": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "sodt_mlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "sodt_debug_wmsa_stamps": [_P, _I],
     "sodt_debug_wmsa_hg_stamps": [_P, _I],

@@ -176,6 +176,9 @@ class Engine:
         self.ddp = None     # set by ddp.attach()
         self.use_fused_wmsa = True     # tests / tools may switch the fused block kernel off to compare with the four launches it replaces
         self.use_fused_mlp = True      # the same for the fused linear MLP (csrc/mlp.hip) against its two GEMM launches
+        # 2x2-conv MLPs (bf16): fc1 folded into the convolution's weights (csrc/convmlp.hip) - no fc1 GEMM, and in the backward no
+        # d(x) = du W1 and no dW1 GEMM; widths above this run the three-GEMM form (the composition kernels are plain f32 loops)
+        self.convmlp_fold_maxc = 192
         # LayerNorm backward as the epilogue of the GEMM that produces its input gradient (SODT_EPI_LNBWD): built and pinned
         # (tests/test_kernels_gpu.py), but measured SLOWER than the two launches it replaces at the bench shapes (0.45 vs 0.34 ms
         # at K = 576: profiles/r04_lnfold_ab.md), so the step does not use it
@@ -443,6 +446,16 @@ class Engine:
                     add(descs_t, p, wc, (4 * Cc, Cc, 1), (0, 2, 1), 2 * Cc)
                     add(descs_t, p2, wc[:, Cc:], (Cc, 4 * Cc, 1), (1, 2, 0), 2 * Cc)
                     wcat[n] = wc
+        # 2x2-conv MLPs with fc1 folded into the convolution: composed weights (re-made every forward by sodt_convmlp_compose)
+        cmlp: Dict[str, Dict[str, torch.Tensor]] = {}
+        if dt == torch.bfloat16:
+            for n, p in self.params.items():
+                if n.endswith("mlp.conv1.weight") and p.dim() == 4 and tuple(p.shape[2:]) == (2, 2) and p.shape[0] == p.shape[1]:
+                    Cc = p.shape[0]
+                    if Cc <= self.convmlp_fold_maxc and Cc % 8 == 0:
+                        cmlp[n[: -len("mlp.conv1.weight")]] = dict(
+                            weff=torch.zeros(Cc, 4 * Cc, device=dev, dtype=dt), weffT=torch.zeros(Cc, 4 * Cc, device=dev, dtype=dt),
+                            beff=torch.zeros(Cc, device=dev), vtap=torch.zeros(4, Cc, device=dev))
         # f32 side: transposed relative-position tables, packed front-end parameters
         bias_t: Dict[str, torch.Tensor] = {}
         for n, p in self.params.items():
@@ -471,7 +484,7 @@ class Engine:
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             mx = max(d.d0 * d.d1 * d.d2 for d in descs)
             return host.to(dev), len(descs), mx
-        P = dict(w=w, wT=wT, wcat=wcat, bias_t=bias_t, fe=fe, tab_t=table(descs_t), tab_f=table(descs_f), dt=dt,
+        P = dict(w=w, wT=wT, wcat=wcat, cmlp=cmlp, bias_t=bias_t, fe=fe, tab_t=table(descs_t), tab_f=table(descs_f), dt=dt,
                  ones={}, keep=(descs_t, descs_f), wmsa=wmsa)
         self.prep[dt] = P
         return P
@@ -738,6 +751,18 @@ class Engine:
                 hp = plan.buf(tag + ".hp", (M, 4 * Cc))
                 ops.gemm_nt([SegSpec(xn2)], w[pre + "mlp.fc1.weight"], hp, M, 4 * Cc, Cc, bias=p[pre + "mlp.fc1.bias"], gelu_out=ha)
             ops.gemm_nt([SegSpec(ha)], w[pre + "mlp.fc2.weight"], xo, M, Cc, 4 * Cc, bias=p[pre + "mlp.fc2.bias"], resid=xm)
+        elif pre in P["cmlp"]:
+            # fc1 folded into the 2x2 convolution (csrc/convmlp.hip): composed weights, the convolution straight on xn2, a correction
+            # on the last column / row (where the padded fc1 output is zero including its bias)
+            cm = P["cmlp"][pre]
+            ops.convmlp_compose(p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.conv1.weight"], p[pre + "mlp.conv1.bias"],
+                                cm["weff"], cm["weffT"], cm["beff"], cm["vtap"], Cc)
+            cp = plan.buf(tag + ".cp", (M, Cc))
+            ca = plan.buf(tag + ".ca", (M, Cc))
+            segs = [SegSpec(xn2, Cc, 0, dy, dx, 1, 0, H, W) for (dy, dx) in TAPS2]
+            ops.gemm_nt(segs, cm["weff"], cp, M, Cc, 4 * Cc, spatial=(H, W), bias=cm["beff"], gelu_out=ca)
+            ops.convmlp_border_fix(cp, ca, cm["vtap"], B, H, W, Cc)
+            ops.gemm_nt([SegSpec(ca)], w[pre + "mlp.fc2.weight"], xo, M, Cc, Cc, bias=p[pre + "mlp.fc2.bias"], resid=xm)
         else:
             u = plan.buf(tag + ".u", (M, Cc))
             ops.gemm_nt([SegSpec(xn2)], w[pre + "mlp.fc1.weight"], u, M, Cc, Cc, bias=p[pre + "mlp.fc1.bias"])
@@ -773,6 +798,22 @@ class Engine:
                             bias=p[pre + "mlp.fc1.bias"], dgelu_rc=True)
             ops.gemm_tn(dh, [SegSpec(xn2)], g[pre + "mlp.fc1.weight"], M, 4 * Cc, Cc, dbias=g[pre + "mlp.fc1.bias"])
             dln2 = (dh, 4 * Cc)
+        elif pre in P["cmlp"]:
+            cm = P["cmlp"][pre]
+            cp, ca = b[tag + ".cp"], b[tag + ".ca"]
+            dc = plan.buf(f"g.dc.{Cc}", (M, Cc))
+            ops.gemm_tn(dY, [SegSpec(ca)], g[pre + "mlp.fc2.weight"], M, Cc, Cc, dbias=g[pre + "mlp.fc2.bias"])
+            ops.gemm_nt([SegSpec(dY)], wT[pre + "mlp.fc2.weight"], dc, M, Cc, Cc, dgelu_aux=cp)
+            # d(Weff) = dc^T xn2(taps) (+ the column sums of dc), then the parameter gradients of fc1 / conv1 by the chain rule
+            scr = plan.buf(f"g.cmlp.{Cc}", (Cc * 4 * Cc + 4 * Cc,), torch.float32)
+            dweff, colsum, bs = scr[: Cc * 4 * Cc].view(Cc, 4 * Cc), scr[Cc * 4 * Cc: Cc * 4 * Cc + Cc], scr[Cc * 4 * Cc + Cc:].view(3, Cc)
+            ops.zero_(scr)
+            segs = [SegSpec(xn2, Cc, 0, dy, dx, 1, 0, H, W) for (dy, dx) in TAPS2]
+            ops.gemm_tn(dc, segs, dweff, M, Cc, 4 * Cc, spatial=(H, W), dbias=colsum)
+            ops.convmlp_border_sums(dc, bs, B, H, W, Cc)
+            ops.convmlp_decompose(dweff, colsum, bs, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.conv1.weight"],
+                                  g[pre + "mlp.conv1.weight"], g[pre + "mlp.conv1.bias"], g[pre + "mlp.fc1.weight"], g[pre + "mlp.fc1.bias"], Cc)
+            dln2 = None           # d(xn2) comes from ONE tap GEMM with the composed weights (no du, no du W1)
         else:
             u, cp, ca = b[tag + ".u"], b[tag + ".cp"], b[tag + ".ca"]
             dc = plan.buf(f"g.dc.{Cc}", (M, Cc))
@@ -788,7 +829,11 @@ class Engine:
             dln2 = (du, Cc)
         # d(xn2) = dln2 @ fc1.weight and the LayerNorm-2 backward (+ the residual path's dY): ONE launch where a token row fits a
         # 192-column tile (stage 1, bf16: SODT_EPI_LNBWD - d(xn2) never goes to HBM), otherwise the GEMM and sodt_layernorm_bwd
-        if self.use_ln_fold and ops.ln_bwd_fold_ok(M, Cc, dln2[1], plan.dt):
+        if dln2 is None:
+            segs = [SegSpec(dc, Cc, 0, -dy, -dx, 1, 0, H, W) for (dy, dx) in TAPS2]
+            ops.gemm_nt(segs, cm["weffT"], dxn, M, Cc, 4 * Cc, spatial=(H, W))
+            ops.layernorm_bwd(dxn, xm, b[tag + ".st2"], p[pre + "norm2.weight"], dY, dxm, g[pre + "norm2.weight"], g[pre + "norm2.bias"], M, Cc)
+        elif self.use_ln_fold and ops.ln_bwd_fold_ok(M, Cc, dln2[1], plan.dt):
             ops.gemm_nt([SegSpec(dln2[0])], wT[pre + "mlp.fc1.weight"], dxm, M, Cc, dln2[1], resid=dY,
                         ln_bwd=(xm, b[tag + ".st2"], p[pre + "norm2.weight"], g[pre + "norm2.weight"], g[pre + "norm2.bias"]))
         else:

@@ -222,6 +222,28 @@ def mlp_fwd(xn: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tens
     _launch("sodt_mlp_fwd", _p(xn), _p(w1), _p(b1), _p(w2), _p(b2), _p(resid), _p(out), _p(hact), M, Cc, dt_code(xn))
 
 
+# ---- 2x2-conv MLP with fc1 folded into the convolution (csrc/convmlp.hip)
+def convmlp_compose(fc1_w, fc1_b, conv_w, conv_b, weff, weffT, beff, vtap, Cc):
+    assert fc1_w.dtype == torch.float32 and conv_w.dtype == torch.float32 and fc1_w.is_contiguous() and conv_w.is_contiguous()
+    assert tuple(conv_w.shape) == (Cc, Cc, 2, 2) and tuple(fc1_w.shape) == (Cc, Cc) and tuple(weff.shape) == (Cc, 4 * Cc) == tuple(weffT.shape)
+    _launch("sodt_convmlp_compose", _p(fc1_w), _p(fc1_b), _p(conv_w), _p(conv_b), _p(weff), _p(weffT), _p(beff), _p(vtap), Cc, dt_code(weff))
+
+
+def convmlp_border_fix(cp, ca, vtap, B, H, W, Cc):
+    _launch("sodt_convmlp_border_fix", _p(cp), _p(ca), _p(vtap), B, H, W, Cc, dt_code(cp))
+
+
+def convmlp_border_sums(dc, bs, B, H, W, Cc):
+    _launch("sodt_convmlp_border_sums", _p(dc), _p(bs), B, H, W, Cc, dt_code(dc))
+
+
+def convmlp_decompose(dweff, colsum, bs, fc1_w, fc1_b, conv_w, g_conv_w, g_conv_b, g_fc1_w, g_fc1_b, Cc):
+    for t in (dweff, colsum, bs, fc1_w, fc1_b, conv_w, g_conv_w, g_conv_b, g_fc1_w, g_fc1_b):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    _launch("sodt_convmlp_decompose", _p(dweff), _p(colsum), _p(bs), _p(fc1_w), _p(fc1_b), _p(conv_w), _p(g_conv_w), _p(g_conv_b),
+            _p(g_fc1_w), _p(g_fc1_b), Cc)
+
+
 def tn_splits(M: int, N: int, K: int, bf16: bool = False) -> int:
     """M-slices per dW tile so that the grid is one full round of workgroups (no tail): 256 x 192 tiles at one
     workgroup per CU when the short side is <= 192, 128 x 128 tiles at two per CU otherwise (csrc/gemm.hip).
