@@ -24,39 +24,58 @@
 
 namespace {
 
-// ---- 32 x 32 output tile of  acc[i][j] = sum_k A(i, k) B(k, j)  by one 256-thread workgroup (f32, K a multiple of 32): 32-deep k chunks
-//      through LDS, thread (ty, tx) = (tid / 16, tid % 16) owns outputs (2 ty .. + 1, 2 tx .. + 1).  la(r, k) / lb(k, c): global loads of one
-//      element of the A / B tile (r, c in 0..31 relative to the tile, k absolute); the callers choose which index runs along the lanes.
+// ---- 64 x 64 output tile of  acc[i][j] = sum_k A(i, k) B(k, j)  by one 256-thread workgroup (f32, K a multiple of 16): 16-deep k chunks
+//      through LDS, thread (ty, tx) = (tid / 16, tid % 16) owns the 4 x 4 outputs (ty + 16 i, tx + 16 j).  la(r, k) / lb(k, c): global loads
+//      of one element of the A / B tile (r, c in 0..63 relative to the tile, k absolute); *_k_fast says which index runs along the lanes.
+constexpr int CT = 64, CK = 16;
 template <typename LA, typename LB>
-__device__ __forceinline__ void tile32(float (&acc)[2][2], int K, float (*As)[33], float (*Bs)[33], LA la, LB lb, bool a_k_fast, bool b_k_fast) {
+__device__ __forceinline__ void tile64(float (&acc)[4][4], int K, float (*As)[CT + 1], float (*Bs)[CT + 1], LA la, LB lb, bool a_k_fast, bool b_k_fast) {
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  for (int k0 = 0; k0 < K; k0 += 32) {
+  // the next chunk's eight global loads are in flight while the current one is multiplied (one workgroup per CU: nothing else hides
+  // their latency - the first version, without the prefetch, took 225 us for the C = 384 decomposition)
+  float pa[4], pb[4];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int idx = tid + 256 * e, hi = idx >> 5, lo = idx & 31;
-      if (a_k_fast) As[hi][lo] = la(hi, k0 + lo); else As[lo][hi] = la(lo, k0 + hi);      // As[row][k]
-      if (b_k_fast) Bs[lo][hi] = lb(k0 + lo, hi); else Bs[hi][lo] = lb(k0 + hi, lo);      // Bs[k][col]
+      const int idx = tid + 256 * e;                         // 1024 elements per operand tile
+      pa[e] = a_k_fast ? la(idx >> 4, k0 + (idx & 15)) : la(idx & 63, k0 + (idx >> 6));
+      pb[e] = b_k_fast ? lb(k0 + (idx & 15), idx >> 4) : lb(k0 + (idx >> 6), idx & 63);
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += CK) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * e;
+      if (a_k_fast) As[idx & 15][idx >> 4] = pa[e]; else As[idx >> 6][idx & 63] = pa[e];      // As[k][row]
+      if (b_k_fast) Bs[idx & 15][idx >> 4] = pb[e]; else Bs[idx >> 6][idx & 63] = pb[e];      // Bs[k][col]
     }
     __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-      const float a0 = As[2 * ty][k], a1 = As[2 * ty + 1][k], b0 = Bs[k][2 * tx], b1 = Bs[k][2 * tx + 1];
-      acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
-      acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+    if (k0 + CK < K) fetch(k0 + CK);
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[k][ty + 16 * i]; b[i] = Bs[k][tx + 16 * i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
     }
     __syncthreads();
   }
 }
 
 // weff[co][t C + ci] = sum_m Wc[co][m][t] W1[m][ci] (and its transposed copy): workgroup (ci tile, co tile, tap); the last grid row
-// (blockIdx.y == C / 32) computes vtap / beff instead
+// (blockIdx.y == C / 64) computes vtap / beff instead
 __global__ __launch_bounds__(256) void convmlp_compose_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                                               const float* __restrict__ Wc, const float* __restrict__ bc,
                                                               bf16* __restrict__ weff, bf16* __restrict__ weffT,
                                                               float* __restrict__ beff, float* __restrict__ vtap, int C) {
-  __shared__ float As[32][33], Bs[32][33];
+  __shared__ float As[CT][CT + 1], Bs[CK][CT + 1];          // (As doubles as the 64 x 64 transposition buffer of the output tile)
   const int tid = threadIdx.x, t = blockIdx.z;
-  if ((int)blockIdx.y == C / 32) {               // vtap[t][co] = Wc_tap b1 for 32 output channels; beff by the tap-0 workgroups
+  if ((int)blockIdx.y == C / CT) {               // vtap[t][co] = Wc_tap b1 for 32 output channels per workgroup; beff with them
+    if (t != 0 || (int)blockIdx.x * 32 >= C) return;
     const int co = blockIdx.x * 32 + (tid >> 3), part = tid & 7;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     for (int m = part; m < C; m += 8) {
@@ -66,30 +85,30 @@ __global__ __launch_bounds__(256) void convmlp_compose_kernel(const float* __res
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { a[j] += __shfl_xor(a[j], 1); a[j] += __shfl_xor(a[j], 2); a[j] += __shfl_xor(a[j], 4); }
-    if (part == 0 && t == 0) {
+    if (part == 0) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) vtap[j * C + co] = a[j];
       beff[co] = bc[co] + a[0] + a[1] + a[2] + a[3];
     }
     return;
   }
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  tile32(acc, C, As, Bs,
+  if ((int)blockIdx.x >= C / CT) return;        // (the grid is C / 32 wide for the vtap row)
+  const int ci0 = blockIdx.x * CT, co0 = blockIdx.y * CT;
+  float acc[4][4] = {};
+  tile64(acc, C, (float (*)[CT + 1])As, Bs,
          [&](int r, int k) { return Wc[((long)(co0 + r) * C + k) * 4 + t]; },
          [&](int k, int c) { return W1[(long)k * C + ci0 + c]; }, true, false);
   const int ty = tid >> 4, tx = tid & 15;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      weff[(long)(co0 + 2 * ty + i) * 4 * C + t * C + ci0 + 2 * tx + j] = (bf16)acc[i][j];
-      As[2 * tx + j][2 * ty + i] = acc[i][j];      // transposed through LDS: [ci][co]
+    for (int j = 0; j < 4; ++j) {
+      weff[(long)(co0 + ty + 16 * i) * 4 * C + t * C + ci0 + tx + 16 * j] = (bf16)acc[i][j];
+      As[tx + 16 * j][ty + 16 * i] = acc[i][j];      // transposed through LDS: [ci][co]
     }
   __syncthreads();
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int idx = tid + 256 * e, r = idx >> 5, c = idx & 31;
+  for (int idx = tid; idx < CT * CT; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
     weffT[(long)(ci0 + r) * 4 * C + t * C + co0 + c] = (bf16)As[r][c];
   }
 }
@@ -153,16 +172,16 @@ __global__ __launch_bounds__(256) void convmlp_border_sums_kernel(const bf16* __
 
 // parameter gradients from d(Weff) [C][4 C] (f32), the column sums of dc and the border sums (all of THIS backward call); the results
 // are ADDED to the gradient buffers (torch layouts).  One launch; workgroup ranges: [0, 4 n) conv1.weight tiles (m tile, co tile, tap),
-// [4 n, 8 n) fc1.weight tiles (ci tile, m tile, quarter of the (co, tap) contraction: f32 atomics), then one workgroup for fc1.bias and
-// conv1.bias; n = (C / 32)^2
+// [4 n, 8 n) fc1.weight tiles (ci tile, m tile, quarter of the (co, tap) contraction: f32 atomics), then C / 32 workgroups for fc1.bias
+// and conv1.bias; n = (C / 64)^2
 __global__ __launch_bounds__(256) void convmlp_decompose_kernel(const float* __restrict__ dweff, const float* __restrict__ colsum,
                                                                 const float* __restrict__ bs, const float* __restrict__ W1,
                                                                 const float* __restrict__ b1, const float* __restrict__ Wc,
                                                                 float* __restrict__ gWc, float* __restrict__ gbc, float* __restrict__ gW1,
                                                                 float* __restrict__ gb1, int C) {
-  __shared__ float As[32][33], Bs[32][33];
+  __shared__ float As[CK][CT + 1], Bs[CK][CT + 1];
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  const int nt = C / 32, n = nt * nt;
+  const int nt = C / CT, n = nt * nt;
   // dv[t][co] = colsum[co] - (sum of dc over the tokens whose tap t is outside): t = 1 right column, t = 2 bottom row, t = 3 either
   auto dv = [&](int t, int co) {
     const float r = bs[co], bt = bs[C + co], cn = bs[2 * C + co];
@@ -171,39 +190,47 @@ __global__ __launch_bounds__(256) void convmlp_decompose_kernel(const float* __r
   int bid = blockIdx.x;
   if (bid < 4 * n) {                               // gWc[co][m][t] += sum_ci dweff[co][t C + ci] W1[m][ci] + dv[t][co] b1[m]
     const int t = bid & 3, tl = bid >> 2;
-    const int m0 = (tl % nt) * 32, co0 = (tl / nt) * 32;
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    tile32(acc, C, As, Bs,
+    const int m0 = (tl % nt) * CT, co0 = (tl / nt) * CT;
+    float acc[4][4] = {};
+    tile64(acc, C, As, Bs,
            [&](int r, int k) { return dweff[(long)(co0 + r) * 4 * C + t * C + k]; },
            [&](int k, int c) { return W1[(long)(m0 + c) * C + k]; }, true, true);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        gWc[((long)(co0 + 2 * ty + i) * C + m0 + 2 * tx + j) * 4 + t] += acc[i][j] + dv(t, co0 + 2 * ty + i) * b1[m0 + 2 * tx + j];
+      for (int j = 0; j < 4; ++j)
+        gWc[((long)(co0 + ty + 16 * i) * C + m0 + tx + 16 * j) * 4 + t] += acc[i][j] + dv(t, co0 + ty + 16 * i) * b1[m0 + tx + 16 * j];
     return;
   }
   bid -= 4 * n;
   if (bid < 4 * n) {                               // gW1[m][ci] += sum_(co, t) Wc[co][m][t] dweff[co][t C + ci]: k = 4 co + t, a quarter of the co's
     const int q = bid & 3, tl = bid >> 2;
-    const int ci0 = (tl % nt) * 32, m0 = (tl / nt) * 32;
+    const int ci0 = (tl % nt) * CT, m0 = (tl / nt) * CT;
     const int kq = q * C;                          // k range [q C, (q + 1) C)
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    tile32(acc, C, As, Bs,
+    float acc[4][4] = {};
+    tile64(acc, C, As, Bs,
            [&](int r, int k) { const int kk = kq + k; return Wc[((long)(kk >> 2) * C + m0 + r) * 4 + (kk & 3)]; },
            [&](int k, int c) { const int kk = kq + k; return dweff[(long)(kk >> 2) * 4 * C + (kk & 3) * C + ci0 + c]; }, true, false);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) atomicAdd(gW1 + (long)(m0 + 2 * ty + i) * C + ci0 + 2 * tx + j, acc[i][j]);
+      for (int j = 0; j < 4; ++j) atomicAdd(gW1 + (long)(m0 + ty + 16 * i) * C + ci0 + tx + 16 * j, acc[i][j]);
     return;
   }
-  for (int m = tid; m < C; m += 256) {             // gb1[m] += sum_t sum_co Wc[co][m][t] dv[t][co];  gbc += colsum
-    float acc = 0.f;
-    for (int co = 0; co < C; ++co) {
-      const float4 wc = *(const float4*)(Wc + ((long)co * C + m) * 4);
-      acc += wc.x * dv(0, co) + wc.y * dv(1, co) + wc.z * dv(2, co) + wc.w * dv(3, co);
-    }
+  // ---- the last C / 32 workgroups: gb1[m] += sum_t sum_co Wc[co][m][t] dv[t][co] and gbc += colsum, 32 values of m each, eight lanes
+  //      per m over the co's (one workgroup walking all of it serially was the longest pole of the launch: 40 of its 51 us at C = 192)
+  bid -= 4 * n;
+  float* dvs = &As[0][0];                          // dv[t][co] in LDS: 4 C floats <= 16 x 65
+  for (int i = tid; i < 4 * C; i += 256) dvs[i] = dv(i / C, i % C);
+  __syncthreads();
+  const int m = bid * 32 + (tid >> 3), part = tid & 7;
+  float acc = 0.f;
+  for (int co = part; co < C; co += 8) {
+    const float4 wc = *(const float4*)(Wc + ((long)co * C + m) * 4);
+    acc += wc.x * dvs[co] + wc.y * dvs[C + co] + wc.z * dvs[2 * C + co] + wc.w * dvs[3 * C + co];
+  }
+  acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+  if (part == 0) {
     gb1[m] += acc;
     gbc[m] += colsum[m];                           // conv1.bias: beff carries bc with coefficient 1
   }
@@ -215,10 +242,10 @@ inline int nblk(long n) { return (int)((n + 255) / 256); }
 
 extern "C" int sodt_convmlp_compose(const float* fc1_w, const float* fc1_b, const float* conv_w, const float* conv_b, void* weff,
                                     void* weffT, float* beff, float* vtap, int C, int dtype, sodt_stream_t st) {
-  if (!fc1_w || !fc1_b || !conv_w || !conv_b || !weff || !weffT || !beff || !vtap || C <= 0 || (C % 32) || dtype != SODT_BF16 ||
+  if (!fc1_w || !fc1_b || !conv_w || !conv_b || !weff || !weffT || !beff || !vtap || C <= 0 || (C % 64) || dtype != SODT_BF16 ||
       (((uintptr_t)conv_w) & 15))
     return SODT_EINVAL;
-  hipLaunchKernelGGL(convmlp_compose_kernel, dim3(C / 32, C / 32 + 1, 4), dim3(256), 0, (hipStream_t)st, fc1_w, fc1_b, conv_w, conv_b,
+  hipLaunchKernelGGL(convmlp_compose_kernel, dim3(C / 32, C / 64 + 1, 4), dim3(256), 0, (hipStream_t)st, fc1_w, fc1_b, conv_w, conv_b,
                      (bf16*)weff, (bf16*)weffT, beff, vtap, C);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
@@ -243,11 +270,11 @@ extern "C" int sodt_convmlp_border_sums(const void* dc, float* bs, int B, int H,
 extern "C" int sodt_convmlp_decompose(const float* dweff, const float* colsum, const float* bs, const float* fc1_w, const float* fc1_b,
                                       const float* conv_w, float* g_conv_w, float* g_conv_b, float* g_fc1_w, float* g_fc1_b, int C,
                                       sodt_stream_t st) {
-  if (!dweff || !colsum || !bs || !fc1_w || !fc1_b || !conv_w || !g_conv_w || !g_conv_b || !g_fc1_w || !g_fc1_b || C <= 0 || (C % 32) ||
+  if (!dweff || !colsum || !bs || !fc1_w || !fc1_b || !conv_w || !g_conv_w || !g_conv_b || !g_fc1_w || !g_fc1_b || C <= 0 || (C % 64) ||
       ((((uintptr_t)conv_w) | ((uintptr_t)g_conv_w)) & 15))
     return SODT_EINVAL;
-  const int n = (C / 32) * (C / 32);
-  hipLaunchKernelGGL(convmlp_decompose_kernel, dim3(8 * n + 1), dim3(256), 0, (hipStream_t)st, dweff, colsum, bs, fc1_w, fc1_b, conv_w,
+  const int n = (C / 64) * (C / 64);
+  hipLaunchKernelGGL(convmlp_decompose_kernel, dim3(8 * n + C / 32), dim3(256), 0, (hipStream_t)st, dweff, colsum, bs, fc1_w, fc1_b, conv_w,
                      g_conv_w, g_conv_b, g_fc1_w, g_fc1_b, C);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }

@@ -178,7 +178,7 @@ class Engine:
         self.use_fused_mlp = True      # the same for the fused linear MLP (csrc/mlp.hip) against its two GEMM launches
         # 2x2-conv MLPs (bf16): fc1 folded into the convolution's weights (csrc/convmlp.hip) - no fc1 GEMM, and in the backward no
         # d(x) = du W1 and no dW1 GEMM; widths above this run the three-GEMM form (the composition kernels are plain f32 loops)
-        self.convmlp_fold_maxc = 192
+        self.convmlp_fold_maxc = 384
         # LayerNorm backward as the epilogue of the GEMM that produces its input gradient (SODT_EPI_LNBWD): built and pinned
         # (tests/test_kernels_gpu.py), but measured SLOWER than the two launches it replaces at the bench shapes (0.45 vs 0.34 ms
         # at K = 576: profiles/r04_lnfold_ab.md), so the step does not use it
@@ -452,7 +452,7 @@ class Engine:
             for n, p in self.params.items():
                 if n.endswith("mlp.conv1.weight") and p.dim() == 4 and tuple(p.shape[2:]) == (2, 2) and p.shape[0] == p.shape[1]:
                     Cc = p.shape[0]
-                    if Cc <= self.convmlp_fold_maxc and Cc % 8 == 0:
+                    if Cc <= self.convmlp_fold_maxc and Cc % 64 == 0:
                         cmlp[n[: -len("mlp.conv1.weight")]] = dict(
                             weff=torch.zeros(Cc, 4 * Cc, device=dev, dtype=dt), weffT=torch.zeros(Cc, 4 * Cc, device=dev, dtype=dt),
                             beff=torch.zeros(Cc, device=dev), vtap=torch.zeros(4, Cc, device=dev))

@@ -23,7 +23,7 @@ def params(dev, Cc, seed=0):
     return W1, b1, Wc, bc
 
 
-@pytest.mark.parametrize("Cc", [192, 64])
+@pytest.mark.parametrize("Cc", [192, 64, 384])
 def test_compose_and_border_terms(ops, dev, Cc):
     W1, b1, Wc, bc = params(dev, Cc)
     weff = torch.zeros(Cc, 4 * Cc, device=dev, dtype=torch.bfloat16)
@@ -40,11 +40,11 @@ def test_compose_and_border_terms(ops, dev, Cc):
     assert float((beff.double() - (bc.double() + vref.sum(0))).abs().max()) <= 1e-5 * float(vref.abs().max() + bc.abs().max())
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (1, 8, 24), (3, 32, 8)])
-def test_folded_forward_and_backward_match_the_reference_form(ops, dev, B, H, W):
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 16, 16, 192), (1, 8, 24, 192), (3, 32, 8, 192), (2, 16, 16, 384)])
+def test_folded_forward_and_backward_match_the_reference_form(ops, dev, B, H, W, Cc):
     """x -> fc1 -> pad -> conv1 -> GELU -> [a linear read-out] on the CPU in f64 with autograd, against: composed weights + tap GEMM +
     border fix (forward), and tap GEMM with the transposed composed weights + weight-gradient GEMM + border sums + decompose (backward)"""
-    Cc, M, dt = 192, B * H * W, torch.bfloat16
+    M, dt = B * H * W, torch.bfloat16
     W1, b1, Wc, bc = params(dev, Cc, seed=10)
     x = rnd((M, Cc), dev, 20, dt=dt)
     dy = rnd((M, Cc), dev, 21, dt=dt)                     # gradient arriving at the conv's pre-activation
@@ -108,7 +108,7 @@ def test_engine_fold_is_as_close_to_the_oracle_as_the_three_gemm_form(dev):
     x_rgb, x_ir = R.synthetic_inputs(Bn, S, seed=3)
     errs = []
     osd = None
-    for maxc in (0, 192):
+    for maxc in (0, 384):
         model, sd = build(dev, S)
         model.compute_dtype = torch.bfloat16
         model.train()
