@@ -282,6 +282,18 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) { acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+  // SODT_EPI_STATS (thin instantiations: the head's BatchNorm convolutions with N <= 64, common.py:38-50): per-lane column sums of v
+  // and v^2 over every tile of this persistent workgroup in f32 (<= 2,048 rows per workgroup at one tile per CU round), reduced over
+  // the 16 rows of a lane group at the end, ONE f64 atomic per column, statistic and wave into the replica buffer (gemm.hip's
+  // weight-stationary kernel does the same per workgroup; per tile it cost 1.4-2.7x: round-1 notes)
+  constexpr bool STATS = (CF & SODT_EPI_STATS) != 0;
+  static_assert(!STATS || NV < 3, "column statistics: thin instantiations only");
+  float st1[STATS ? NV : 1][8], st2[STATS ? NV : 1][8];
+#pragma unroll
+  for (int t = 0; t < (STATS ? NV : 1); ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st1[t][j] = 0.f; st2[t][j] = 0.f; }
+
   // ---- prologue: A(0), W(0), A(1)
   issue_a(0);
   issue_b(0);
@@ -435,7 +447,13 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
             v[0] += __uint_as_float(b0.x); v[1] += __uint_as_float(b0.y); v[2] += __uint_as_float(b0.z); v[3] += __uint_as_float(b0.w);
             v[4] += __uint_as_float(b1.x); v[5] += __uint_as_float(b1.y); v[6] += __uint_as_float(b1.z); v[7] += __uint_as_float(b1.w);
           }
-          constexpr int CF2 = CF & ~(SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_DGELU | SODT_EPI_DGELU_RC | SODT_EPI_DRELU);
+          constexpr int CF2 = CF & ~(SODT_EPI_BIAS | SODT_EPI_RESID | SODT_EPI_DGELU | SODT_EPI_DGELU_RC | SODT_EPI_DRELU | SODT_EPI_STATS);
+          if constexpr (STATS) {
+            if (m < g.M && n < g.N) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { st1[t][j] += v[j]; st2[t][j] = fmaf(v[j], v[j], st2[t][j]); }
+            }
+          }
           if (m < g.M && n < g.N) {
             if constexpr (OSC) epi_chunk<bf16, -1>(g, CF2, m, n, v, hw);      // (generic path: knows the row scatter)
             else epi_chunk<bf16, CF2>(g, CF2, m, n, v, hw);
@@ -447,6 +465,22 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(const sodt_gemm_args g) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the dummy tail DMAs must land before the LDS is released
+  if constexpr (STATS) {
+    if (wc == 0) {
+#pragma unroll
+      for (int t = 0; t < NV; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float a = group16_sum(st1[t][j]), b = group16_sum(st2[t][j]);
+          const int n = 32 * t + 8 * fg + j;                 // (one column tile: n0 = 0)
+          if (fi == 0 && n < g.N) {
+            double* st = g.stats + (size_t)((blockIdx.x * 4 + wr) % SODT_STATS_REPL) * 2 * g.N;
+            atomicAdd(st + n, (double)a);
+            atomicAdd(st + g.N + n, (double)b);
+          }
+        }
+    }
+  }
 }
 
 template <int CF, bool OSC = false, int NV = 3>
@@ -1098,6 +1132,9 @@ bool sodt_nt3_eligible(const sodt_gemm_args* g) {
     case 0: case SODT_EPI_BIAS: case SODT_EPI_RESID: case SODT_EPI_BIAS | SODT_EPI_RESID:
     case SODT_EPI_BIAS | SODT_EPI_GELU_DUAL: case SODT_EPI_DGELU: case SODT_EPI_BIAS | SODT_EPI_GELU: break;
     case SODT_EPI_RELU: case SODT_EPI_BIAS | SODT_EPI_RELU: case SODT_EPI_DRELU: break;      // the SR branch's convolutions (sr.py)
+    case SODT_EPI_STATS:                           // the head's BatchNorm convolutions, thin outputs only (one column tile, NV = 2)
+      if (g->N > 64 || !g->stats || g->oscatter) return false;
+      break;
     case SODT_EPI_BIAS | SODT_EPI_DGELU_RC:
       if (g->K % (2 * T3_BK)) return false;        // both halves whole K-steps
       break;
@@ -1107,7 +1144,8 @@ bool sodt_nt3_eligible(const sodt_gemm_args* g) {
   // N: whole 192-column tiles, or (K >= 512) any multiple of 8 with the last tile partial - a narrow output (the 64-channel 3x3
   // convolutions of the SR branch, the 256-wide ones of its tail) is priced by the A stream, which this kernel moves by LDS-DMA
   // three stages ahead; the idle accumulator columns cost matrix cycles that are not the bound there
-  if (g->N % 8 || (g->N % T3_BN && (g->K < 512 || g->K > T3_MAXKLEN)) || g->K % T3_BK || g->K < 192 || g->M < T3_BM) return false;
+  const int kmin_partial = g->flags == SODT_EPI_STATS ? 192 : 512;     // (statistics: the alternative is the 128 x 128 K-loop kernel)
+  if (g->N % 8 || (g->N % T3_BN && (g->K < kmin_partial || g->K > T3_MAXKLEN)) || g->K % T3_BK || g->K < 192 || g->M < T3_BM) return false;
   if ((g->flags & SODT_EPI_RESID) && (g->ldr % 8)) return false;
   if ((g->flags & (SODT_EPI_DGELU | SODT_EPI_DRELU)) && (g->ldaux % 8)) return false;
   if ((g->flags & SODT_EPI_BIAS) && g->N > T3_MAXBIAS) return false;
@@ -1126,6 +1164,7 @@ int sodt_nt3_launch(const sodt_gemm_args* g, hipStream_t st) {
       case SODT_EPI_RESID: return launch_nt3<SODT_EPI_RESID, false, 2>(g, st);
       case SODT_EPI_BIAS | SODT_EPI_RELU: return launch_nt3<SODT_EPI_BIAS | SODT_EPI_RELU, false, 2>(g, st);
       case SODT_EPI_DRELU: return launch_nt3<SODT_EPI_DRELU, false, 2>(g, st);
+      case SODT_EPI_STATS: return launch_nt3<SODT_EPI_STATS, false, 2>(g, st);
       default: break;
     }
   }

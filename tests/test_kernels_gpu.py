@@ -110,6 +110,40 @@ def test_gemm_nt_stats_affine_detect(ops, dev, dt, variant):
     close(pred, refp, dt, what="detect")
 
 
+@pytest.mark.parametrize("M,N,K,taps", [(2048 + 77, 64, 384, 0), (4096, 64, 576, 9), (256 * 300 + 5, 64, 192, 0), (1024, 32, 576, 0)])
+def test_gemm_nt_pipelined_thin_with_bn_statistics(ops, dev, M, N, K, taps):
+    """the head's BatchNorm convolutions with N <= 64 (C3 at the stride-4 level, common.py:38-50,76-90) on the pipelined kernel's thin
+    instantiation: the output and the f64 column sums of v and v^2 (per-lane f32 partial sums over the workgroup's tiles, one f64 atomic
+    per wave - round 5) against f64; a 3x3 tap form, ragged M, several tiles per workgroup (> 256 tiles)"""
+    dt = torch.bfloat16
+    W = rnd((N, K), dev, dt, 2, 1 / math.sqrt(K))
+    if taps:
+        Cc = K // taps
+        H = int(math.isqrt(M // 4))
+        B = 4
+        M = B * H * H
+        x = rnd((M, Cc), dev, dt, 1)
+        segs = [ops.SegSpec(x, Cc, 0, dy, dx, 1, 0, H, H) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+        kw = dict(spatial=(H, H))
+        xi = x.float().view(B, H, H, Cc).permute(0, 3, 1, 2)
+        wconv = W.float().view(N, 9, Cc).permute(0, 2, 1).reshape(N, Cc, 3, 3)
+        ref = F.conv2d(xi.double(), wconv.double(), padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    else:
+        A = rnd((M, K), dev, dt, 1)
+        segs, kw = [ops.SegSpec(A)], {}
+        ref = A.double() @ W.double().t()
+    out = torch.full((M + 2, N), float("nan"), device=dev, dtype=dt)
+    stats = torch.zeros(16, 2, N, device=dev, dtype=torch.float64)
+    ops.gemm_nt(segs, W, out[:M], M, N, K, stats=stats, **kw)
+    torch.cuda.synchronize()
+    assert torch.isnan(out[M:]).all()
+    close(out[:M], ref, dt, what="z")
+    s1, s2 = stats.sum(0)[0].cpu(), stats.sum(0)[1].cpu()
+    r1, r2 = ref.sum(0).cpu(), (ref * ref).sum(0).cpu()
+    assert float((s2 - r2).abs().max()) <= 1e-3 * float(r2.abs().max()), "sum of squares"
+    assert float((s1 - r1).abs().max()) <= 1e-3 * float(r2.abs().max().sqrt() * math.sqrt(M)), "sum"
+
+
 def _nhwc(x):   # (B,C,H,W) -> token-major (B*H*W, C)
     B, Cc, H, W = x.shape
     return x.permute(0, 2, 3, 1).reshape(B * H * W, Cc).contiguous()
