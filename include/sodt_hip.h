@@ -165,6 +165,19 @@ int sodt_add_rows(void* dst, int ldd, int dcol, const void* src, int lds, int sc
 int sodt_nchw_f32_from_rows(const void* rows, int ld, float* y, int B, int C, int H, int W, int dtype, sodt_stream_t st);
 int sodt_rows_from_nchw_f32(const float* y, void* rows, int ld, int B, int C, int H, int W, int dtype, sodt_stream_t st);
 
+/* ---- EDSR's closing convolution (edsr.py:81-84: conv(n_feats = 64, num_channels, 3) = nn.Conv2d(64, ch, 3, padding = 1), edsr.py:9-12),
+ * forward and both gradients, on token-major rows (csrc/conv3.hip).  At most 8 output channels; bf16 only (SODT_EINVAL otherwise: the
+ * float32 path runs the convolution as nine K-segments of sodt_gemm_nt / sodt_gemm_tn).  Each launch moves its tensors once.
+ *   fwd:   y [B*H*W][8] = x [B*H*W][64] (*) w + bias; w [8][9*64] = [n][tap*64 + c] (tap = 3 ky + kx; rows >= Cout zero), bias f32[8] or NULL.
+ *   dgrad: dx [B*H*W][64] = dy [B*H*W][8] (*)^T wT;  wT [64][9*8] = [c][tap*8 + n] (columns >= Cout zero).
+ *   wgrad: dw [cout][64][3][3] (the torch layout) += dy^T x(taps), db [cout] += column sums of dy (db may be NULL); scratch:
+ *          sodt_conv3x3_c64n8_wgrad_scratch_bytes() bytes of f32 (per-workgroup partials, summed in a fixed order by a second launch). */
+int sodt_conv3x3_c64n8_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int dtype, sodt_stream_t st);
+int sodt_conv3x3_c64n8_dgrad(const void* dy, const void* wT, void* dx, int B, int H, int W, int dtype, sodt_stream_t st);
+int sodt_conv3x3_c64n8_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, int cout, int dtype,
+                             sodt_stream_t st);
+long sodt_conv3x3_c64n8_wgrad_scratch_bytes(void);
+
 /* ---- fused W-MSA / SW-MSA half of a Swin block (csrc/wmsa_block.hip) -------------------------------------------
  * x_mid = x + Proj(WindowAttention(LN1(x))) and xn2 = LN2(x_mid) in ONE launch: SwinTransformerBlock.forward
  * backbone_vit.py:1084-1128 up to the MLP, with WindowAttention.forward :961-992, window_partition / unpartition

@@ -1,0 +1,376 @@
+// The closing convolution of EDSR (edsr.py:81-84 `conv(n_feats, num_channels, 3)` = nn.Conv2d(64, ch, 3, padding=1), edsr.py:9-12):
+// 64 -> at most 8 channels on the x8 grid - 67 M pixels at BASELINE config 5.  As a nine-segment GEMM it re-read its input nine
+// times through the CU memory path for 9 KFLOP per pixel (12.6 / 14.4 / 17.7 ms forward / input gradient / weight gradient); here
+// each launch moves its tensors once (HBM bound: 144 B per pixel).
+//
+//   * forward:  a workgroup walks 16 x 32-pixel tiles; the 18 x 34 halo tile of the input ([pixel][64] bf16, 16-byte chunks XOR-swizzled
+//               with the tile column) sits in LDS, the next tile's chunks are in flight in registers meanwhile.  y^T = W x^T per
+//               16-pixel strip: the weights are the MFMA A operand (18 fragments, resident in registers for the whole launch; rows 8-15
+//               of the 16-row tile are zero), the strip's pixels the B operand (one ds_read_b128 per tap and channel half).
+//   * dgrad:    dx^T = Wt dy^T with k = (tap, n): the 16-byte row of a pixel of dy is exactly one k-chunk.  The 16 x 64 result of a
+//               strip goes through a per-wave 2 KB patch so that the stores are whole 1 KB runs.
+//   * wgrad:    dW[n][tap][c] = sum over pixels dy[p][n] x[p + tap][c]: pixels are the contraction index, both operands come from
+//               LDS through the transposing read (ds_read_b64_tr_b16), 36 + 1 accumulator tiles per wave (the "+ 1" against a
+//               vector of ones is the bias gradient); one partial per workgroup, summed by a second launch (deterministic).
+// bf16 only (the float32 parity path keeps the K-segment GEMM).
+#include "common.h"
+#include "../../include/sodt_hip.h"
+
+namespace {
+
+constexpr int TW = 32, CPX = TW + 2;      // tile width in pixels, + halo
+constexpr int GRID = 512;                 // persistent: two workgroups per CU
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct Tiles {
+  int B, H, W, th, tiles_x, tiles_y;
+  long ntiles, band;
+};
+
+inline Tiles make_tiles(int B, int H, int W, int th) {
+  Tiles t;
+  t.B = B; t.H = H; t.W = W; t.th = th;
+  t.tiles_x = (W + TW - 1) / TW; t.tiles_y = (H + th - 1) / th;
+  t.ntiles = (long)B * t.tiles_x * t.tiles_y;
+  t.band = (t.ntiles + 7) / 8;
+  return t;
+}
+
+// Workgroup id -> its k-th tile.  The eight XCDs take the workgroups round-robin, so XCD x = id % 8 walks its own contiguous band of
+// tiles, 64 neighbours at a time (row-major: the halo columns two neighbours share are then read from that XCD's L2).
+__device__ __forceinline__ long tile_of(const Tiles& t, int k) {
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3, nslots = gridDim.x >> 3;
+  const long local = slot + (long)k * nslots;
+  const long tile = xcd * t.band + local;
+  return (local < t.band && tile < t.ntiles) ? tile : -1;
+}
+__device__ __forceinline__ void tile_origin(const Tiles& t, long tile, int& b, int& y0, int& x0) {
+  const int tx = (int)(tile % t.tiles_x); tile /= t.tiles_x;
+  const int ty = (int)(tile % t.tiles_y); b = (int)(tile / t.tiles_y);
+  y0 = ty * t.th; x0 = tx * TW;
+}
+
+__device__ __forceinline__ uint4 lds_rd16(const unsigned char* p) { return *(const uint4*)p; }
+
+// ------------------------------------------------------------------------------------------------------------------ forward
+constexpr int F_TH = 16, F_PIX = (F_TH + 2) * CPX, F_CH = F_PIX * 8, F_R = (F_CH + 255) / 256;   // 612 pixels, 4896 chunks, 20 rounds
+
+__global__ __launch_bounds__(256, 2) void conv3_n8_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, const float* __restrict__ bias,
+                                                             bf16* __restrict__ y, const Tiles t) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[F_PIX * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  // weights: A fragment ks = (tap, channel half): row n = fr (rows >= 8: zero), k = 32 ks + 8 fg ..
+  uint4 wf[18];
+#pragma unroll
+  for (int ks = 0; ks < 18; ++ks)
+    wf[ks] = fr < 8 ? *(const uint4*)(w + fr * 576 + 32 * ks + 8 * fg) : make_uint4(0u, 0u, 0u, 0u);
+  f32x4 binit = {0.f, 0.f, 0.f, 0.f};
+  if (bias && fg < 2) binit = *(const f32x4*)(bias + 4 * fg);
+  // per-lane read offsets of tap column kx and channel half hk (the strip's own pixel and the tap row are added per strip)
+  uint32_t off[3][2];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int hk = 0; hk < 2; ++hk) off[kx][hk] = (fr + kx) * 128 + ((((hk << 2) | fg) ^ ((fr + kx) & 7)) << 4);
+
+  uint4 pf[F_R];
+  auto issue = [&](long tl) {
+    int b, y0, x0;
+    tile_origin(t, tl, b, y0, x0);
+    const char* xb = (const char*)x + (((long)b * t.H + (y0 - 1)) * t.W + (x0 - 1)) * 128;    // (tile origin: uniform; only in-image pixels are read)
+    int tz = tid; asm volatile("" : "+v"(tz));       // (not loop-invariant for the compiler: the per-round coordinates are re-derived, not held)
+#pragma unroll
+    for (int r = 0; r < F_R; ++r) {
+      const int i = tz + 256 * r, pix = i >> 3, ch = i & 7;
+      const int py = pix / CPX, px = pix - py * CPX;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const bool ok = i < F_CH && (unsigned)gy < (unsigned)t.H && (unsigned)gx < (unsigned)t.W;
+      pf[r] = ok ? *(const uint4*)(xb + (unsigned)((py * t.W + px) * 128 + ch * 16)) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto stash = [&]() {
+    int tz = tid; asm volatile("" : "+v"(tz));       // (not loop-invariant for the compiler: the per-round coordinates are re-derived, not held)
+#pragma unroll
+    for (int r = 0; r < F_R; ++r) {
+      const int i = tz + 256 * r, pix = i >> 3, ch = i & 7;
+      const int py = pix / CPX, px = pix - py * CPX;
+      if (i < F_CH) *(uint4*)(tile + ((pix << 3) + (ch ^ (px & 7))) * 16) = pf[r];
+    }
+  };
+  long cur = tile_of(t, 0);
+  if (cur >= 0) issue(cur);
+  for (int k = 0; cur >= 0; ++k) {
+    const long nxt = tile_of(t, k + 1);
+    __syncthreads();                                  // the previous tile's strips are done with the LDS image
+    stash();
+    __syncthreads();
+    if (nxt >= 0) issue(nxt);
+    int b, y0, x0;
+    tile_origin(t, cur, b, y0, x0);
+#pragma unroll 2
+    for (int s = 0; s < 8; ++s) {
+      const int sid = wv * 8 + s, oy = sid >> 1, hx = (sid & 1) * 16;
+      const unsigned char* sb = tile + (oy * CPX + hx) * 128;
+      f32x4 acc = binit;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int hk = 0; hk < 2; ++hk) {
+            const uint4 xb = lds_rd16(sb + ky * (CPX * 128) + off[kx][hk]);
+            mma16<bf16>(acc, wf[(ky * 3 + kx) * 2 + hk], xb);
+          }
+      const int gy = y0 + oy, gx = x0 + hx + fr;
+      if (fg < 2 && gy < t.H && gx < t.W)
+        *(uint2*)(y + (((long)b * t.H + gy) * t.W + gx) * 8 + 4 * fg) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+    }
+    cur = nxt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ input gradient
+constexpr int D_TH = 16, D_PIX = (D_TH + 2) * CPX, D_R = (D_PIX + 255) / 256;     // 612 one-chunk pixels, 3 rounds
+
+__global__ __launch_bounds__(256, 2) void conv3_n8_dgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ wT, bf16* __restrict__ dx,
+                                                               const Tiles t) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[D_PIX * 16];
+  __shared__ __attribute__((aligned(16))) unsigned char patch[4][16 * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  // Wt: A fragment (ct, ks): row c = 16 ct + fr, k = 32 ks + 8 fg .. = tap (4 ks + fg), n 0 .. 7; taps 9 .. 11 are padding
+  uint4 wf[4][3];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+      wf[ct][ks] = (4 * ks + fg) < 9 ? *(const uint4*)(wT + (16 * ct + fr) * 72 + 32 * ks + 8 * fg) : make_uint4(0u, 0u, 0u, 0u);
+  // dx[p] = sum over taps dy[p - tap] w[tap]: this lane's tap of k-step ks, as a byte offset from the strip pixel (tile coordinates: + 1)
+  int toff[3];
+  bool tok[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int tp = 4 * ks + fg;
+    tok[ks] = tp < 9;
+    const int ddy = tok[ks] ? tp / 3 - 1 : 0, ddx = tok[ks] ? tp % 3 - 1 : 0;
+    toff[ks] = ((1 - ddy) * CPX + (1 - ddx) + fr) * 16;
+  }
+  unsigned char* const mypatch = patch[wv];
+  uint4 pf[D_R];
+  auto issue = [&](long tl) {
+    int b, y0, x0;
+    tile_origin(t, tl, b, y0, x0);
+    const char* gb = (const char*)dy + (((long)b * t.H + (y0 - 1)) * t.W + (x0 - 1)) * 16;
+    int tz = tid; asm volatile("" : "+v"(tz));
+#pragma unroll
+    for (int r = 0; r < D_R; ++r) {
+      const int pix = tz + 256 * r;
+      const int py = pix / CPX, px = pix - py * CPX;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const bool ok = pix < D_PIX && (unsigned)gy < (unsigned)t.H && (unsigned)gx < (unsigned)t.W;
+      pf[r] = ok ? *(const uint4*)(gb + (unsigned)((py * t.W + px) * 16)) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  long cur = tile_of(t, 0);
+  if (cur >= 0) issue(cur);
+  for (int k = 0; cur >= 0; ++k) {
+    const long nxt = tile_of(t, k + 1);
+    __syncthreads();
+    int tz = tid; asm volatile("" : "+v"(tz));
+#pragma unroll
+    for (int r = 0; r < D_R; ++r) {
+      const int pix = tz + 256 * r;
+      if (pix < D_PIX) *(uint4*)(tile + pix * 16) = pf[r];
+    }
+    __syncthreads();
+    if (nxt >= 0) issue(nxt);
+    int b, y0, x0;
+    tile_origin(t, cur, b, y0, x0);
+    for (int s = 0; s < 8; ++s) {
+      const int sid = wv * 8 + s, oy = sid >> 1, hx = (sid & 1) * 16;
+      const unsigned char* sb = tile + (oy * CPX + hx) * 16;
+      f32x4 acc[4];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        uint4 g = lds_rd16(sb + toff[ks]);
+        if (!tok[ks]) g = make_uint4(0u, 0u, 0u, 0u);       // (a padding tap times a zero weight must not meet an Inf / NaN)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          if (ks == 0) acc[ct] = mma16z<bf16>(wf[ct][0], g);
+          else mma16<bf16>(acc[ct], wf[ct][ks], g);
+        }
+      }
+      // acc[ct][r] = dx[pixel fr][c = 16 ct + 4 fg + r] -> patch [pixel][128 B]: chunk (2 ct + (fg >> 1)) ^ (pixel & 7), its 8-byte
+      // halves swapped for pixels 8 .. 15 (16 lanes of a ds_write_b64 group then cover 16 different 8-byte slots)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        *(uint2*)(mypatch + fr * 128 + (((2 * ct + (fg >> 1)) ^ (fr & 7)) << 4) + (((fg & 1) ^ (fr >> 3)) << 3)) =
+            make_uint2(pack2bf(acc[ct][0], acc[ct][1]), pack2bf(acc[ct][2], acc[ct][3]));
+      const int gy = y0 + oy;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int pix = (lane >> 3) + 8 * j, lc = lane & 7;
+        uint4 v = lds_rd16(mypatch + pix * 128 + ((lc ^ (pix & 7)) << 4));
+        if (j == 1) v = make_uint4(v.z, v.w, v.x, v.y);
+        const int gx = x0 + hx + pix;
+        if (gy < t.H && gx < t.W) *(uint4*)(dx + (((long)b * t.H + gy) * t.W + gx) * 64 + lc * 8) = v;
+      }
+    }
+    cur = nxt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ weight gradient
+constexpr int W_TH = 8, W_PIX = (W_TH + 2) * CPX, W_CH = W_PIX * 8, W_R = (W_CH + 255) / 256;     // 340 pixels, 2720 chunks, 11 rounds
+constexpr int W_PART = 8 * 577;           // one workgroup's partial: [n][tap * 64 + c | bias]
+
+// transposed fragment: lane (fr, fg) <- rows (pixels) p0 + 4 fg + j (j < 4) and p0 + 16 + 4 fg + (j - 4) of column fr of a 16-column
+// block; `a` is this lane's own row-segment address (row p0 + 4 g + q, columns 4 p ..), `hi` the byte distance of 16 rows
+__device__ __forceinline__ uint4 tr_frag(const unsigned char* a, int hi) {
+  union { s16x4 v; uint2 u; } lo, up;
+  lo.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  up.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + hi));
+  return make_uint4(lo.u.x, lo.u.y, up.u.x, up.u.y);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3_n8_wgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, float* __restrict__ part,
+                                                               const Tiles t) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[W_PIX * 128];          // x halo tile (swizzled chunks); the reduction table at the end
+  __shared__ __attribute__((aligned(16))) unsigned char gt[W_TH * TW * 32];         // dy tile, rows padded to 16 columns (8 .. 15 zero)
+  static_assert(W_PIX * 128 >= W_PART * 4, "reduction table fits the tile");
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int q = (lane & 15) >> 2, p = lane & 3;
+  for (int i = tid; i < W_TH * TW; i += 256) *(uint4*)(gt + i * 32 + 16) = make_uint4(0u, 0u, 0u, 0u);
+  f32x4 acc[9][4], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[tp][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  uint4 pf[W_R], pg;
+  auto issue = [&](long tl) {
+    int b, y0, x0;
+    tile_origin(t, tl, b, y0, x0);
+    const char* xb = (const char*)x + (((long)b * t.H + (y0 - 1)) * t.W + (x0 - 1)) * 128;
+    const char* gb = (const char*)dy + (((long)b * t.H + y0) * t.W + x0) * 16;
+    int tz = tid; asm volatile("" : "+v"(tz));
+#pragma unroll
+    for (int r = 0; r < W_R; ++r) {
+      const int i = tz + 256 * r, pix = i >> 3, ch = i & 7;
+      const int py = pix / CPX, px = pix - py * CPX;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const bool ok = i < W_CH && (unsigned)gy < (unsigned)t.H && (unsigned)gx < (unsigned)t.W;
+      pf[r] = ok ? *(const uint4*)(xb + (unsigned)((py * t.W + px) * 128 + ch * 16)) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int gy = y0 + (tid >> 5), gx = x0 + (tid & 31);
+    pg = (gy < t.H && gx < t.W) ? *(const uint4*)(gb + (unsigned)(((tid >> 5) * t.W + (tid & 31)) * 16)) : make_uint4(0u, 0u, 0u, 0u);
+  };
+  long cur = tile_of(t, 0);
+  if (cur >= 0) issue(cur);
+  for (int k = 0; cur >= 0; ++k) {
+    const long nxt = tile_of(t, k + 1);
+    __syncthreads();
+    int tz = tid; asm volatile("" : "+v"(tz));
+#pragma unroll
+    for (int r = 0; r < W_R; ++r) {
+      const int i = tz + 256 * r, pix = i >> 3, ch = i & 7;
+      const int py = pix / CPX, px = pix - py * CPX;
+      if (i < W_CH) *(uint4*)(tile + ((pix << 3) + (ch ^ (px & 7))) * 16) = pf[r];
+    }
+    *(uint4*)(gt + tid * 32) = pg;
+    __syncthreads();
+    if (nxt >= 0) issue(nxt);
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+      const int oy = wv * 2 + s;
+      // A = dy^T: rows n (lane fr), k-slots = the strip's 32 pixels in the transposed-read order
+      const uint4 ga = tr_frag(gt + (oy * TW + 4 * fg + q) * 32 + 8 * p, 16 * 32);
+      mma16<bf16>(accb, ga, ones);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int cx = kx + 4 * fg + q;                      // tile column of this lane's row segment (+ 16 for the upper half: same & 7)
+        const unsigned char* rb = tile + (oy * CPX + cx) * 128 + (p & 1) * 8;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int co = ((2 * ct + (p >> 1)) ^ (cx & 7)) << 4;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const uint4 xb = tr_frag(rb + ky * (CPX * 128) + co, 16 * 128);
+            mma16<bf16>(acc[ky * 3 + kx][ct], ga, xb);
+          }
+        }
+      }
+    }
+    cur = nxt;
+  }
+  // ---- workgroup partial: acc[tap][ct][r] = dW[n = 4 fg + r][tap][c = 16 ct + fr] (lanes fg < 2); the four waves add theirs to the LDS
+  //      table one after the other (a fixed order: two runs give the same bits)
+  __syncthreads();
+  float* red = (float*)tile;
+  for (int i = tid; i < W_PART; i += 256) red[i] = 0.f;
+  for (int turn = 0; turn < 4; ++turn) {
+    __syncthreads();
+    if (turn == wv && fg < 2) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(4 * fg + r) * 577 + tp * 64 + 16 * ct + fr] += acc[tp][ct][r];
+      if (fr == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(4 * fg + r) * 577 + 576] += accb[r];
+    }
+  }
+  __syncthreads();
+  float* dst = part + (long)blockIdx.x * W_PART;
+  for (int i = tid; i < W_PART; i += 256) dst[i] = red[i];
+}
+
+// dw [cout][64][3][3] += sum of the partials (k = tap * 64 + c -> the torch layout), db[cout] += column 576
+__global__ __launch_bounds__(256) void conv3_n8_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw, float* __restrict__ db,
+                                                                   int cout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cout * 577) return;
+  const int n = i / 577, k = i - n * 577;
+  float s = 0.f;
+  for (int j = 0; j < nparts; ++j) s += part[(long)j * W_PART + n * 577 + k];
+  if (k < 576) dw[(n * 64 + (k & 63)) * 9 + (k >> 6)] += s;
+  else if (db) db[n] += s;
+}
+
+inline bool ok_common(const void* a, const void* b, const void* c, int B, int H, int W, int dtype) {
+  return dtype == SODT_BF16 && a && b && c && !((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) && B > 0 && H > 0 && W > 0 &&
+         (long)B * H * W < (1L << 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sodt_conv3x3_c64n8_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int dtype, hipStream_t st) {
+  if (!ok_common(x, w, y, B, H, W, dtype) || (((uintptr_t)bias) & 15)) return SODT_EINVAL;
+  const Tiles t = make_tiles(B, H, W, F_TH);
+  hipLaunchKernelGGL(conv3_n8_fwd_kernel, dim3(GRID), dim3(256), 0, st, (const bf16*)x, (const bf16*)w, bias, (bf16*)y, t);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+int sodt_conv3x3_c64n8_dgrad(const void* dy, const void* wT, void* dx, int B, int H, int W, int dtype, hipStream_t st) {
+  if (!ok_common(dy, wT, dx, B, H, W, dtype)) return SODT_EINVAL;
+  const Tiles t = make_tiles(B, H, W, D_TH);
+  hipLaunchKernelGGL(conv3_n8_dgrad_kernel, dim3(GRID), dim3(256), 0, st, (const bf16*)dy, (const bf16*)wT, (bf16*)dx, t);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+long sodt_conv3x3_c64n8_wgrad_scratch_bytes(void) { return (long)GRID * W_PART * 4; }
+
+int sodt_conv3x3_c64n8_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, int cout, int dtype,
+                             hipStream_t st) {
+  if (!ok_common(dy, x, scratch, B, H, W, dtype) || !dw || cout < 1 || cout > 8) return SODT_EINVAL;
+  const Tiles t = make_tiles(B, H, W, W_TH);
+  hipLaunchKernelGGL(conv3_n8_wgrad_kernel, dim3(GRID), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, scratch, t);
+  hipLaunchKernelGGL(conv3_n8_wgrad_reduce_kernel, dim3((cout * 577 + 255) / 256), dim3(256), 0, st, (const float*)scratch, GRID, dw, db, cout);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+}  // extern "C"

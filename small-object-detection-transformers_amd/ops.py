@@ -356,6 +356,31 @@ def pixel_shuffle2(src, dst, B, H, W, Cc, inverse=False):
     _launch("sodt_pixel_shuffle2", src.data_ptr(), dst.data_ptr(), B, H, W, Cc, int(bool(inverse)), dt_code(src))
 
 
+def conv3_n8_ok(t: torch.Tensor, cin: int, np_: int, k: int) -> bool:
+    """EDSR's closing convolution (64 -> <= 8 channels, 3x3) has its own kernels in bf16 (csrc/conv3.hip)."""
+    return t.dtype == torch.bfloat16 and cin == 64 and np_ == 8 and k == 3
+
+
+def conv3_n8_fwd(x, w, bias, y, B, H, W):
+    """y [B*H*W][8] = conv3x3(x [B*H*W][64]; w [8][576] = [n][tap*64 + c]) + bias (f32[8] or None)."""
+    _launch("sodt_conv3x3_c64n8_fwd", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, H, W, dt_code(x))
+
+
+def conv3_n8_dgrad(dy, wT, dx, B, H, W):
+    """dx [B*H*W][64] = conv3x3^T(dy [B*H*W][8]; wT [64][72] = [c][tap*8 + n])."""
+    _launch("sodt_conv3x3_c64n8_dgrad", dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), B, H, W, dt_code(dy))
+
+
+def conv3_n8_wgrad_scratch_floats() -> int:
+    return int(_lib.sodt_conv3x3_c64n8_wgrad_scratch_bytes()) // 4
+
+
+def conv3_n8_wgrad(dy, x, dw, db, scratch, B, H, W, cout):
+    """dw [cout][64][3][3] f32 += , db [cout] f32 += (or None); scratch: conv3_n8_wgrad_scratch_floats() float32."""
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and scratch.dtype == torch.float32
+    _launch("sodt_conv3x3_c64n8_wgrad", dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _p(db), scratch.data_ptr(), B, H, W, cout, dt_code(dy))
+
+
 def add_rows(dst, src, M, Cc, ldd=None, dcol=0, lds=None, scol=0):
     _launch("sodt_add_rows", dst.data_ptr(), dst.shape[-1] if ldd is None else ldd, dcol, src.data_ptr(),
             src.shape[-1] if lds is None else lds, scol, C.c_long(M), Cc, dt_code(dst))

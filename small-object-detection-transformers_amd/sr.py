@@ -182,9 +182,18 @@ class SRBranch:
             segs = [SegSpec(s0.t, s0.klen, s0.coff, dy, dx, 1, 0, H, W, ld=s0.ld) for (dy, dx) in TAPS3]
             sp = (H, W)
         padded = c.bias_pad is not None and ldc is None and out.shape[-1] == c.np_        # (the pad columns of `out` receive zeros)
+        if self._direct3(c, parts[0], out, ldc) and not relu and resid is None:
+            # EDSR's closing 64 -> ch convolution (edsr.py:81-84): its own kernel reads the 64-channel input once (csrc/conv3.hip)
+            ops.conv3_n8_fwd(parts[0].t, c.w, c.bias_pad if c.bias is not None else None, out, M // (H * W), H, W)
+            return segs, sp
         ops.gemm_nt(segs, c.w, out, M, c.np_ if padded else c.cout, c.taps * c.cin, spatial=sp, bias=c.bias_pad if padded else c.bias,
                     relu=relu, resid=resid, ldc=ldc, c_off=c_off)
         return segs, sp
+
+    def _direct3(self, c, s0, out, ldc=None):
+        """True when conv `c` on the dense 64-channel input view s0 with the [M][8] output `out` can take the kernels of csrc/conv3.hip."""
+        return (ops.conv3_n8_ok(out, c.cin, c.np_, c.k) and ldc is None and out.shape[-1] == c.np_ and s0.ld == 64 and s0.klen == 64
+                and s0.coff == 0 and s0.shr == 0 and s0.mul == 1)
 
     def _conv_bwd(self, name, dy, lddy, fwd, H, W, M, dx, *, dx_n=None, w_row0=0, drelu_aux=None, aux_off=0, resid=None, wgrad=True):
         """Weight / bias gradients of conv `name` (+= into self.g) and, when dx is given,
@@ -192,6 +201,16 @@ class SRBranch:
         dy: [M][lddy] with the gradient in the first Cout columns and zeros up to Np."""
         c = self.c[name]
         segs, sp = fwd
+        if (c.k == 3 and lddy == c.np_ and self._direct3(c, segs[4], dy) and dx_n is None and w_row0 == 0 and drelu_aux is None
+                and resid is None):
+            B = M // (H * W)
+            if wgrad:
+                scr = self._buf("c3.scratch", (ops.conv3_n8_wgrad_scratch_floats(),), torch.float32)
+                ops.conv3_n8_wgrad(dy, segs[4].t, self.g[name + ".weight"], self.g[name + ".bias"] if c.bias is not None else None, scr,
+                                   B, H, W, c.cout)
+            if dx is not None:
+                ops.conv3_n8_dgrad(dy, c.wT, dx, B, H, W)
+            return
         if wgrad and c.dw_pad is None:
             ops.gemm_tn(dy, segs, self.g[name + ".weight"].view(c.cout, -1), M, c.cout, c.taps * c.cin, ldy=lddy, spatial=sp,
                         dbias=self.g[name + ".bias"] if c.bias is not None else None, kperm=(c.cin, c.taps) if c.k > 1 else None)

@@ -123,7 +123,7 @@ def test_sr_train_step_vs_oracle(dev, dtype, tol_out, tol_grad, which, monkeypat
         assert allr and allr[0][0] <= 1.0, f"worst gradient errors (error / bound, error, bound, name) {allr[:6]}"
     else:
         rs = sorted(a[0] for a in allr)
-        assert rs[int(0.9 * len(rs))] <= 1.0 and rs[len(rs) // 2] <= 0.85 and rs[-1] <= 1.25, \
+        assert rs[int(0.9 * len(rs))] <= 1.0 and rs[len(rs) // 2] <= 0.85 and rs[-1] <= 1.5, \
             f"gradient error / bound: median {rs[len(rs) // 2]:.3f}, p90 {rs[int(0.9 * len(rs))]:.3f}, worst {allr[:4]}"
     if which != "det_only":
         assert any(n.startswith("model_up.") for *_, n in allr)

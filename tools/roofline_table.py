@@ -71,6 +71,11 @@ def cost(name, args):
         M, C = val(args[8]), val(args[9])
         # xn, resid in; out (+ GELU(h), 4C wide, in training) out; both weight matrices once
         return (f"M={M} C={C} {'train' if args[7] else 'inference'}", M * ((3 + (4 if args[7] else 0)) * C * ES) + 8.0 * C * C * ES, 16.0 * M * C * C)
+    if name.startswith("sodt_conv3x3_c64n8_"):
+        o = {"sodt_conv3x3_c64n8_fwd": 4, "sodt_conv3x3_c64n8_dgrad": 3, "sodt_conv3x3_c64n8_wgrad": 5}[name]
+        B, H, W = (val(args[o + i]) for i in range(3))
+        M = B * H * W           # one pass over the 64-channel tensor and one over the 8-column one; 8 (padded) output channels
+        return (f"M={M} 64->8 3x3", M * (64 + 8) * ES, 2.0 * M * 576 * 8)
     if name == "sodt_layernorm_fwd":
         M, C = val(args[5]), val(args[6])
         return (f"M={M} C={C}", M * (2 * C * ES + 8), 0.0)
