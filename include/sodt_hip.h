@@ -178,6 +178,20 @@ int sodt_conv3x3_c64n8_wgrad(const void* dy, const void* x, float* dw, float* db
                              sodt_stream_t st);
 long sodt_conv3x3_c64n8_wgrad_scratch_bytes(void);
 
+/* ---- the 3x3 convolutions of EDSR's body at 64 -> 64 channels (edsr.py:34-53 ResBlock: conv -> ReLU -> conv, + x; :64-70 head and
+ * body-closing convolutions), token-major rows, bf16 only (csrc/conv3.hip): the input tile crosses the CU once, the weights live in registers.
+ *   sodt_conv3x3_c64_fwd: y [B*H*W][64] = epilogue(x [B*H*W][64] (*) w); w [64][9*64] = [n][tap*64 + c].  flip != 0 mirrors the taps
+ *     (tap' = 8 - tap): with w = the transposed weights [c][tap*64 + n] and x = dy this is the input gradient.  flags: any of
+ *     SODT_EPI_BIAS (bias f32[64]), SODT_EPI_RELU, SODT_EPI_DRELU (aux [B*H*W][64]: keep where aux > 0), SODT_EPI_RESID (resid
+ *     [B*H*W][64]), applied in that order as in sodt_gemm_nt; anything else is SODT_EINVAL.
+ *   sodt_conv3x3_c64_wgrad: dw [64][64][3][3] (torch layout) += dy^T x(taps), db [64] += column sums of dy (or NULL); scratch:
+ *     sodt_conv3x3_c64_wgrad_scratch_bytes() bytes (per-workgroup partials, summed in a fixed order by a second launch). */
+int sodt_conv3x3_c64_fwd(const void* x, const void* w, const float* bias, const void* resid, const void* aux, void* y, int B, int H, int W,
+                         int flags, int flip, int dtype, sodt_stream_t st);
+int sodt_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, int dtype,
+                           sodt_stream_t st);
+long sodt_conv3x3_c64_wgrad_scratch_bytes(void);
+
 /* ---- fused W-MSA / SW-MSA half of a Swin block (csrc/wmsa_block.hip) -------------------------------------------
  * x_mid = x + Proj(WindowAttention(LN1(x))) and xn2 = LN2(x_mid) in ONE launch: SwinTransformerBlock.forward
  * backbone_vit.py:1084-1128 up to the MLP, with WindowAttention.forward :961-992, window_partition / unpartition

@@ -131,6 +131,8 @@ SIGNATURES = {
     "sodt_conv3x3_c64n8_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sodt_conv3x3_c64n8_dgrad": [_P, _P, _P, _I, _I, _I, _I, _P],
     "sodt_conv3x3_c64n8_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sodt_conv3x3_c64_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sodt_conv3x3_c64_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sodt_debug_wmsa_stamps": [_P, _I],
     "sodt_debug_wmsa_hg_stamps": [_P, _I],
 }
@@ -158,6 +160,8 @@ def load():
     lib.sodt_frontend_bwd_workspace_bytes.restype = C.c_long
     lib.sodt_conv3x3_c64n8_wgrad_scratch_bytes.argtypes = []
     lib.sodt_conv3x3_c64n8_wgrad_scratch_bytes.restype = C.c_long
+    lib.sodt_conv3x3_c64_wgrad_scratch_bytes.argtypes = []
+    lib.sodt_conv3x3_c64_wgrad_scratch_bytes.restype = C.c_long
     lib.sodt_version.restype = C.c_char_p
     lib.sodt_version.argtypes = []
     _lib = lib
@@ -166,4 +170,4 @@ def load():
 
 def exported_symbols():
     return list(SIGNATURES.keys()) + ["sodt_version", "sodt_wmsa_pack_bytes", "sodt_frontend_bwd_workspace_bytes",
-                                           "sodt_conv3x3_c64n8_wgrad_scratch_bytes"]
+                                           "sodt_conv3x3_c64n8_wgrad_scratch_bytes", "sodt_conv3x3_c64_wgrad_scratch_bytes"]

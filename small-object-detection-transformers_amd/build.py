@@ -62,7 +62,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             for s in ex.map(compile_one, jobs):
                 if verbose:
                     print(f"[build] compiled {os.path.basename(s)}", flush=True)
-    if jobs or not os.path.exists(LIB):
+    if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):      # (objects built by hand count too)
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

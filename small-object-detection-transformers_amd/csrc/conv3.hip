@@ -339,6 +339,295 @@ __global__ __launch_bounds__(256) void conv3_n8_wgrad_reduce_kernel(const float*
   else if (db) db[n] += s;
 }
 
+// ================================================================================================== 64 -> 64 channels (EDSR's body)
+// The residual blocks (edsr.py:34-53: conv -> ReLU -> conv, + x) and the head / closing convolutions of the body are 3x3 at 64 -> 64
+// channels.  8 x 32-pixel tiles (10 x 34 halo tile in LDS), one 8-wave workgroup per CU: wave (w, h) owns the OUTPUT channels 16 w ..
+// 16 w + 15 (its 18 weight fragments resident in registers) of the 16-pixel strip h of all eight tile rows, so no weight ever goes
+// through LDS and the input crosses the CU once.  flip: the input gradient is the same correlation with the taps mirrored (tap' = 8 - tap) and the transposed weights.
+// Epilogue in the GEMM's order: + bias, ReLU, ReLU mask (aux > 0), + residual.
+// Every global access of the hot path is UNCONDITIONAL (out-of-image halo chunks read a zero buffer; tiles that stick out of the image
+// take a second, predicated instantiation): hipcc then counts vmcnt exactly, so the epilogue operands that are fetched four rows ahead
+// and the next tile's chunks stay in flight across the rows - with a predicated load anywhere in the loop it falls back to vmcnt(0)
+// before every row and the wave eats a memory latency sixteen times per tile.
+struct C64Args {
+  const bf16* x; const bf16* w; const float* bias; const bf16* resid; const bf16* aux; bf16* y;
+  int flags, flip;
+};
+
+__device__ __attribute__((aligned(16))) unsigned int c3_zero16[4] = {0u, 0u, 0u, 0u};
+
+constexpr int C_TH = 8, C_PIX = (C_TH + 2) * CPX, C_CH = C_PIX * 8, C_R = (C_CH + 511) / 512;   // 340 pixels, 2720 chunks, 6 rounds of 512 threads
+
+// One tile: wave (w, h) owns output channels 16 w .. 16 w + 15 of the 16-pixel strip h of every tile row and slides down the ten halo
+// rows.  The six fragments of halo row r (three tap columns x two channel halves) are read ONCE and feed the three output rows r, r - 1,
+// r - 2 (tap rows 0, 1, 2), whose accumulators roll through acc[row % 3]: a third of the LDS reads of a row-by-row walk (which left LDS
+// and the matrix pipe each ~50 % busy, one after the other).  The next row's fragments are read behind this row's MFMAs
+// (sched_group_barrier; hipcc would sink every read next to its MFMA and pay an LDS latency per pair).
+template <bool FULL, bool HAS_E>
+__device__ __forceinline__ void c64_rows(const C64Args& a, const Tiles& t, const unsigned char* tile, const uint4 (&wf)[18], const uint32_t (&off)[3][2],
+                                         const f32x4 binit, int b, int y0, int x0, int n0, int h, int fr) {
+  const bool relu = a.flags & SODT_EPI_RELU, drelu = HAS_E && (a.flags & SODT_EPI_DRELU), res = HAS_E && (a.flags & SODT_EPI_RESID);
+  const bf16* eop = drelu ? a.aux : a.resid;         // (at most one of the two: checked by the entry point)
+  const long tb = (((long)b * t.H + y0) * t.W + x0 + 16 * h) * 64 + n0;
+  const bool colok = FULL || x0 + 16 * h + fr < t.W;
+  uint2 re[4];
+  auto ldrow = [&](int row, uint2& q) {
+    if (!HAS_E) return;
+    // FULL: no predicated access anywhere in the loop (hipcc then counts vmcnt exactly and the loads stay in flight across rows)
+    const bool ok = FULL || (colok && y0 + row < t.H);
+    q = ok ? *(const uint2*)(eop + tb + (unsigned)((row * t.W + fr) * 64)) : make_uint2(0u, 0u);
+  };
+#pragma unroll
+  for (int jr = 0; jr < 4; ++jr) ldrow(jr, re[jr]);
+  f32x4 acc[3];
+  uint4 fq[2][6];                                     // fragments of two consecutive halo rows
+  auto rd = [&](int r, uint4 (&f)[6]) {
+    const unsigned char* sb = tile + (r * CPX + 16 * h) * 128;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) { f[2 * kx] = lds_rd16(sb + off[kx][0]); f[2 * kx + 1] = lds_rd16(sb + off[kx][1]); }
+  };
+  rd(0, fq[0]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < C_TH + 2; ++r) {
+    if (r + 1 < C_TH + 2) rd(r + 1, fq[(r + 1) & 1]);
+    int nmm = 0;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int oy = r - ky;
+          if (oy >= 0 && oy < C_TH) {
+            if (ky == 0 && kx == 0 && hk == 0) acc[oy % 3] = binit;
+            mma16<bf16>(acc[oy % 3], wf[(ky * 3 + kx) * 2 + hk], fq[r & 1][2 * kx + hk]);
+            ++nmm;
+          }
+        }
+    if (r + 1 < C_TH + 2) {                            // pin: one LDS read behind every third (second, first) MFMA of the row
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        if (nmm == 18) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        else if (nmm == 12) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // (the next row's MFMAs must not be pulled up next to "their" reads)
+    if (r >= 2) {
+      const int oy = r - 2, jr = oy & 3;
+      if (FULL || (colok && y0 + oy < t.H)) {
+        f32x4 v = acc[oy % 3];
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (drelu) {
+          const uint2 q = re[jr];
+          // bf16 > 0  <=>  sign clear and not zero
+          if (!((q.x & 0x7fffu) && !(q.x & 0x8000u))) v[0] = 0.f;
+          if (!((q.x & 0x7fff0000u) && !(q.x & 0x80000000u))) v[1] = 0.f;
+          if (!((q.y & 0x7fffu) && !(q.y & 0x8000u))) v[2] = 0.f;
+          if (!((q.y & 0x7fff0000u) && !(q.y & 0x80000000u))) v[3] = 0.f;
+        }
+        if (res) {
+          const uint2 q = re[jr];
+          v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xffff0000u);
+          v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xffff0000u);
+        }
+        *(uint2*)(a.y + tb + (unsigned)((oy * t.W + fr) * 64)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+      if (oy + 4 < C_TH) ldrow(oy + 4, re[jr]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void conv3_c64_kernel(const C64Args a, const Tiles t) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[C_PIX * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wv = wave & 3, h = wave >> 2, fr = lane & 15, fg = lane >> 4;
+  uint4 wf[18];
+#pragma unroll
+  for (int ks = 0; ks < 18; ++ks) {
+    const int tp = ks >> 1, col = (a.flip ? 8 - tp : tp) * 64 + (ks & 1) * 32 + 8 * fg;
+    wf[ks] = *(const uint4*)(a.w + (16 * wv + fr) * 576 + col);
+  }
+  const int n0 = 16 * wv + 4 * fg;
+  f32x4 binit = {0.f, 0.f, 0.f, 0.f};
+  if (a.flags & SODT_EPI_BIAS) binit = *(const f32x4*)(a.bias + n0);
+  uint32_t off[3][2];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int hk = 0; hk < 2; ++hk) off[kx][hk] = (fr + kx) * 128 + ((((hk << 2) | fg) ^ ((fr + kx) & 7)) << 4);
+
+  uint4 pf[C_R];
+  auto issue = [&](long tl) {
+    int b, y0, x0;
+    tile_origin(t, tl, b, y0, x0);
+    const char* xb = (const char*)a.x + (((long)b * t.H + (y0 - 1)) * t.W + (x0 - 1)) * 128;
+    int tz = tid; asm volatile("" : "+v"(tz));
+#pragma unroll
+    for (int r = 0; r < C_R; ++r) {
+      const int i = tz + 512 * r, pix = i >> 3, ch = i & 7;
+      const int py = pix / CPX, px = pix - py * CPX;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const bool ok = i < C_CH && (unsigned)gy < (unsigned)t.H && (unsigned)gx < (unsigned)t.W;
+      pf[r] = ok ? *(const uint4*)(xb + (unsigned)((py * t.W + px) * 128 + ch * 16)) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto stash = [&]() {
+    int tz = tid; asm volatile("" : "+v"(tz));
+#pragma unroll
+    for (int r = 0; r < C_R; ++r) {
+      const int i = tz + 512 * r, pix = i >> 3, ch = i & 7;
+      const int py = pix / CPX, px = pix - py * CPX;
+      if (i < C_CH) *(uint4*)(tile + ((pix << 3) + (ch ^ (px & 7))) * 16) = pf[r];
+    }
+  };
+  long cur = tile_of(t, 0);
+  if (cur >= 0) issue(cur);
+  for (int k = 0; cur >= 0; ++k) {
+    const long nxt = tile_of(t, k + 1);
+    __syncthreads();
+    stash();
+    __syncthreads();
+    if (nxt >= 0) issue(nxt);
+    int b, y0, x0;
+    tile_origin(t, cur, b, y0, x0);
+    const bool full = y0 + C_TH <= t.H && x0 + TW <= t.W;
+    if (a.flags & (SODT_EPI_DRELU | SODT_EPI_RESID)) {
+      if (full) c64_rows<true, true>(a, t, tile, wf, off, binit, b, y0, x0, n0, h, fr);
+      else c64_rows<false, true>(a, t, tile, wf, off, binit, b, y0, x0, n0, h, fr);
+    } else {
+      if (full) c64_rows<true, false>(a, t, tile, wf, off, binit, b, y0, x0, n0, h, fr);
+      else c64_rows<false, false>(a, t, tile, wf, off, binit, b, y0, x0, n0, h, fr);
+    }
+    cur = nxt;
+  }
+}
+
+// weight gradient, 64 -> 64: dW[n][tap][c] = sum_p dy[p][n] x[p + tap][c].  Eight waves: wave (w = n-tile, e = strip parity) keeps the 36 + 1
+// accumulator tiles of its 16 output channels; both operands come from LDS through the transposing read, every wave reads every x
+// fragment of its strips.  One partial [64][577] per (workgroup, parity), summed by the reduce launch.
+constexpr int G_TH = 8, G_XCH = (G_TH + 2) * CPX * 8, G_XR = (G_XCH + 511) / 512, G_YCH = G_TH * TW * 8, G_YR = G_YCH / 512;   // 2720 / 6, 2048 / 4
+constexpr int G_PART = 64 * 577;
+
+__global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, float* __restrict__ part,
+                                                                const Tiles t) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[(G_TH + 2) * CPX * 128];     // x halo tile
+  __shared__ __attribute__((aligned(16))) unsigned char gt[G_TH * TW * 128];              // dy tile (chunks swizzled with the pixel's column)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wv = wave & 3, par = wave >> 2, fr = lane & 15, fg = lane >> 4;
+  f32x4 acc[9][4], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[tp][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+  uint4 pf[G_XR], pg[G_YR];
+  auto issue = [&](long tl) {
+    int b, y0, x0;
+    tile_origin(t, tl, b, y0, x0);
+    const char* xb = (const char*)x + (((long)b * t.H + (y0 - 1)) * t.W + (x0 - 1)) * 128;
+    const char* gb = (const char*)dy + (((long)b * t.H + y0) * t.W + x0) * 128;
+    int tz = tid; asm volatile("" : "+v"(tz));
+#pragma unroll
+    for (int r = 0; r < G_XR; ++r) {
+      const int i = tz + 512 * r, pix = i >> 3, ch = i & 7;
+      const int py = pix / CPX, px = pix - py * CPX;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const bool ok = i < G_XCH && (unsigned)gy < (unsigned)t.H && (unsigned)gx < (unsigned)t.W;
+      pf[r] = ok ? *(const uint4*)(xb + (unsigned)((py * t.W + px) * 128 + ch * 16)) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < G_YR; ++r) {
+      const int i = tz + 512 * r, pix = i >> 3, ch = i & 7;
+      const int py = pix >> 5, px = pix & 31;
+      const bool ok = y0 + py < t.H && x0 + px < t.W;
+      pg[r] = ok ? *(const uint4*)(gb + (unsigned)((py * t.W + px) * 128 + ch * 16)) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  long cur = tile_of(t, 0);
+  if (cur >= 0) issue(cur);
+  for (int k = 0; cur >= 0; ++k) {
+    const long nxt = tile_of(t, k + 1);
+    __syncthreads();
+    {
+      int tz = tid; asm volatile("" : "+v"(tz));
+#pragma unroll
+      for (int r = 0; r < G_XR; ++r) {
+        const int i = tz + 512 * r, pix = i >> 3, ch = i & 7;
+        const int py = pix / CPX, px = pix - py * CPX;
+        if (i < G_XCH) *(uint4*)(tile + ((pix << 3) + (ch ^ (px & 7))) * 16) = pf[r];
+      }
+#pragma unroll
+      for (int r = 0; r < G_YR; ++r) {
+        const int i = tz + 512 * r, pix = i >> 3, ch = i & 7;
+        *(uint4*)(gt + ((pix << 3) + (ch ^ (pix & 7))) * 16) = pg[r];
+      }
+    }
+    __syncthreads();
+    if (nxt >= 0) issue(nxt);
+#pragma unroll 1
+    for (int s = 0; s < G_TH / 2; ++s) {
+      const int oy = 2 * s + par;
+      int lz = lane; asm volatile("" : "+v"(lz));          // (lane-derived offsets re-derived per strip: as loop invariants they are spilled)
+      const int p = lz & 3, ox = (lz >> 4) * 4 + ((lz & 15) >> 2);   // this lane's row segment: strip pixel ox (and ox + 16: same & 7)
+      const uint4 ga = tr_frag(gt + (oy * TW + ox) * 128 + (((2 * wv + (p >> 1)) ^ (ox & 7)) << 4) + (p & 1) * 8, 16 * 128);
+      mma16<bf16>(accb, ga, ones);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int cx = kx + ox;
+        const unsigned char* rb = tile + (oy * CPX + cx) * 128 + (p & 1) * 8;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int co = ((2 * ct + (p >> 1)) ^ (cx & 7)) << 4;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const uint4 xb = tr_frag(rb + ky * (CPX * 128) + co, 16 * 128);
+            mma16<bf16>(acc[ky * 3 + kx][ct], ga, xb);
+          }
+        }
+      }
+    }
+    cur = nxt;
+  }
+  // acc[tap][ct][r] = dW[n = 16 wv + 4 fg + r][tap][c = 16 ct + fr]: every (wave, lane, r) owns its own entries of the partial
+  float* dst = part + ((long)blockIdx.x * 2 + par) * G_PART;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(16 * wv + 4 * fg + r) * 577 + tp * 64 + 16 * ct + fr] = acc[tp][ct][r];
+  if (fr == 0)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(16 * wv + 4 * fg + r) * 577 + 576] = accb[r];
+}
+
+// dw += the sum of the partials in a fixed order: a block owns 64 consecutive entries, its four waves take every fourth partial (256-byte
+// row reads), LDS adds the four sums
+__global__ __launch_bounds__(256) void conv3_c64_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (i < G_PART) {
+    int j = g;
+    for (; j + 12 < nparts; j += 16) {
+      const float a0 = part[(long)j * G_PART + i], a1 = part[(long)(j + 4) * G_PART + i], a2 = part[(long)(j + 8) * G_PART + i],
+                  a3 = part[(long)(j + 12) * G_PART + i];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; j < nparts; j += 4) s += part[(long)j * G_PART + i];
+  }
+  sm[g][lane] = s;
+  __syncthreads();
+  if (g == 0 && i < G_PART) {
+    s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    const int n = i / 577, k = i - n * 577;
+    if (k < 576) dw[(n * 64 + (k & 63)) * 9 + (k >> 6)] += s;
+    else if (db) db[n] += s;
+  }
+}
+
 inline bool ok_common(const void* a, const void* b, const void* c, int B, int H, int W, int dtype) {
   return dtype == SODT_BF16 && a && b && c && !((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) && B > 0 && H > 0 && W > 0 &&
          (long)B * H * W < (1L << 31);
@@ -370,6 +659,32 @@ int sodt_conv3x3_c64n8_wgrad(const void* dy, const void* x, float* dw, float* db
   const Tiles t = make_tiles(B, H, W, W_TH);
   hipLaunchKernelGGL(conv3_n8_wgrad_kernel, dim3(GRID), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, scratch, t);
   hipLaunchKernelGGL(conv3_n8_wgrad_reduce_kernel, dim3((cout * 577 + 255) / 256), dim3(256), 0, st, (const float*)scratch, GRID, dw, db, cout);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+int sodt_conv3x3_c64_fwd(const void* x, const void* w, const float* bias, const void* resid, const void* aux, void* y, int B, int H, int W,
+                         int flags, int flip, int dtype, hipStream_t st) {
+  if (!ok_common(x, w, y, B, H, W, dtype) || ((((uintptr_t)bias) | ((uintptr_t)resid) | ((uintptr_t)aux)) & 15)) return SODT_EINVAL;
+  if (flags & ~(SODT_EPI_BIAS | SODT_EPI_RELU | SODT_EPI_DRELU | SODT_EPI_RESID)) return SODT_EINVAL;
+  if (((flags & SODT_EPI_BIAS) && !bias) || ((flags & SODT_EPI_RESID) && !resid) || ((flags & SODT_EPI_DRELU) && !aux)) return SODT_EINVAL;
+  if ((flags & SODT_EPI_RESID) && (flags & SODT_EPI_DRELU)) return SODT_EINVAL;       // one epilogue operand per launch (no layer of the branch has both)
+  C64Args a;
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.resid = (const bf16*)resid; a.aux = (const bf16*)aux; a.y = (bf16*)y;
+  a.flags = flags; a.flip = flip ? 1 : 0;
+  const Tiles t = make_tiles(B, H, W, C_TH);
+  const int grid = (int)(t.ntiles < GRID / 2 ? ((t.ntiles + 7) / 8) * 8 : GRID / 2);       // one 8-wave workgroup per CU
+  hipLaunchKernelGGL(conv3_c64_kernel, dim3(grid), dim3(512), 0, st, a, t);
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+long sodt_conv3x3_c64_wgrad_scratch_bytes(void) { return (long)(GRID / 2) * 2 * G_PART * 4; }
+
+int sodt_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, int dtype, hipStream_t st) {
+  if (!ok_common(dy, x, scratch, B, H, W, dtype) || !dw) return SODT_EINVAL;
+  const Tiles t = make_tiles(B, H, W, G_TH);
+  const int grid = (int)(t.ntiles < GRID / 2 ? ((t.ntiles + 7) / 8) * 8 : GRID / 2);       // one 8-wave workgroup per CU
+  hipLaunchKernelGGL(conv3_c64_wgrad_kernel, dim3(grid), dim3(512), 0, st, (const bf16*)dy, (const bf16*)x, scratch, t);
+  hipLaunchKernelGGL(conv3_c64_wgrad_reduce_kernel, dim3((G_PART + 63) / 64), dim3(256), 0, st, (const float*)scratch, 2 * grid, dw, db);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 

@@ -182,6 +182,10 @@ class SRBranch:
             segs = [SegSpec(s0.t, s0.klen, s0.coff, dy, dx, 1, 0, H, W, ld=s0.ld) for (dy, dx) in TAPS3]
             sp = (H, W)
         padded = c.bias_pad is not None and ldc is None and out.shape[-1] == c.np_        # (the pad columns of `out` receive zeros)
+        if self._direct64(c, parts[0], out, ldc):
+            # EDSR's 64 -> 64 convolutions (head, the ResBlocks, the body's closing one: edsr.py:34-53, :64-70)
+            ops.conv3_c64_fwd(parts[0].t, c.w, out, M // (H * W), H, W, bias=c.bias, relu=relu, resid=resid)
+            return segs, sp
         if self._direct3(c, parts[0], out, ldc) and not relu and resid is None:
             # EDSR's closing 64 -> ch convolution (edsr.py:81-84): its own kernel reads the 64-channel input once (csrc/conv3.hip)
             ops.conv3_n8_fwd(parts[0].t, c.w, c.bias_pad if c.bias is not None else None, out, M // (H * W), H, W)
@@ -195,12 +199,26 @@ class SRBranch:
         return (ops.conv3_n8_ok(out, c.cin, c.np_, c.k) and ldc is None and out.shape[-1] == c.np_ and s0.ld == 64 and s0.klen == 64
                 and s0.coff == 0 and s0.shr == 0 and s0.mul == 1)
 
+    @staticmethod
+    def _direct64(c, s0, out, ldc=None):
+        """True when conv `c` is a 3x3 at 64 -> 64 channels on dense bf16 rows (csrc/conv3.hip: sodt_conv3x3_c64_*)."""
+        return (out.dtype == torch.bfloat16 and c.k == 3 and c.cin == 64 and c.cout == 64 and ldc is None and out.shape[-1] == 64
+                and s0.ld == 64 and s0.klen == 64 and s0.coff == 0 and s0.shr == 0 and s0.mul == 1)
+
     def _conv_bwd(self, name, dy, lddy, fwd, H, W, M, dx, *, dx_n=None, w_row0=0, drelu_aux=None, aux_off=0, resid=None, wgrad=True):
         """Weight / bias gradients of conv `name` (+= into self.g) and, when dx is given,
         dx = conv^T(dy) for input channels [w_row0, w_row0 + dx_n), masked by drelu_aux > 0, + resid.
         dy: [M][lddy] with the gradient in the first Cout columns and zeros up to Np."""
         c = self.c[name]
         segs, sp = fwd
+        if c.k == 3 and lddy == 64 and self._direct64(c, segs[4], dy) and dx_n is None and w_row0 == 0 and aux_off == 0:
+            B = M // (H * W)
+            if wgrad:
+                scr = self._buf("c64.scratch", (ops.conv3_c64_wgrad_scratch_floats(),), torch.float32)
+                ops.conv3_c64_wgrad(dy, segs[4].t, self.g[name + ".weight"], self.g[name + ".bias"] if c.bias is not None else None, scr, B, H, W)
+            if dx is not None:
+                ops.conv3_c64_fwd(dy, c.wT, dx, B, H, W, drelu_aux=drelu_aux, resid=resid, flip=True)
+            return
         if (c.k == 3 and lddy == c.np_ and self._direct3(c, segs[4], dy) and dx_n is None and w_row0 == 0 and drelu_aux is None
                 and resid is None):
             B = M // (H * W)

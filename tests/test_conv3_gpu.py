@@ -127,6 +127,95 @@ def test_many_tiles_per_workgroup_bit_identical_to_itself_and_close_to_the_gemm_
     assert (db1 - dyd[:, :cout].float().sum(0)).abs().max().item() <= 1e-3 * dyd.float().abs().sum(0).max().item()
 
 
+C64_SHAPES = [(1, 16, 32), (2, 20, 40), (1, 50, 70), (1, 3, 5), (2, 96, 160)]
+
+
+@pytest.mark.parametrize("B,H,W", C64_SHAPES)
+def test_body_convolution_64_to_64_vs_float64_conv2d(ops, B, H, W):
+    """sodt_conv3x3_c64_fwd (every epilogue the ResBlocks use, forward and mirrored-tap input gradient) and sodt_conv3x3_c64_wgrad
+    (edsr.py:34-53) against float64 F.conv2d autograd on the same bf16 operands."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11 * H + W)
+    M = B * H * W
+    x = torch.randn(B, H, W, 64, generator=g).bfloat16()
+    r = torch.randn(B, H, W, 64, generator=g).bfloat16()
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.04).bfloat16()
+    b = torch.randn(64, generator=g) * 0.1
+    dy = torch.randn(B, H, W, 64, generator=g).bfloat16()
+    wg = w.permute(0, 2, 3, 1).reshape(64, 576).contiguous().to(dev)            # [n][tap * 64 + c]
+    wT = w.permute(1, 2, 3, 0).reshape(64, 576).contiguous().to(dev)            # [c][tap * 64 + n]
+    xd, rd, dyd, bd = x.reshape(M, 64).to(dev), r.reshape(M, 64).to(dev), dy.reshape(M, 64).to(dev), b.to(dev)
+    x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    ref = F.conv2d(x64, w64, b64, padding=1)
+    refr = ref.detach().permute(0, 2, 3, 1)
+    r64 = r.double()
+
+    def check(got, want, what):
+        got = got.float().cpu().view(B, H, W, 64).double()
+        assert (got - want).norm().item() <= 2.5e-3 * want.norm().item(), what
+        assert (got - want).abs().max().item() <= 8e-3 * want.abs().max().item(), what
+
+    y = torch.empty(M, 64, device=dev, dtype=torch.bfloat16)
+    ops.conv3_c64_fwd(xd, wg, y, B, H, W, bias=bd, relu=True)
+    check(y, refr.clamp_min(0), "bias + ReLU")
+    ops.conv3_c64_fwd(xd, wg, y, B, H, W, bias=bd, resid=rd)
+    check(y, refr + r64, "bias + residual")
+    ops.conv3_c64_fwd(xd, wg, y, B, H, W)
+    check(y, refr - b.double(), "plain")
+
+    ref.backward(dy.double().permute(0, 3, 1, 2))
+    rdx = x64.grad.permute(0, 2, 3, 1)
+    dx = torch.empty(M, 64, device=dev, dtype=torch.bfloat16)
+    ops.conv3_c64_fwd(dyd, wT, dx, B, H, W, flip=True)
+    check(dx, rdx, "input gradient")
+    ops.conv3_c64_fwd(dyd, wT, dx, B, H, W, flip=True, drelu_aux=rd)
+    check(dx, rdx * (r64 > 0), "input gradient x ReLU mask")
+    ops.conv3_c64_fwd(dyd, wT, dx, B, H, W, flip=True, resid=rd)
+    check(dx, rdx + r64, "input gradient + residual path")
+    with pytest.raises(RuntimeError):        # one epilogue operand per launch (no layer of the branch has both)
+        ops.conv3_c64_fwd(dyd, wT, dx, B, H, W, flip=True, drelu_aux=xd, resid=rd)
+
+    dw = torch.full((64, 64, 3, 3), 0.5, device=dev)
+    db = torch.full((64,), -0.25, device=dev)
+    scr = torch.empty(ops.conv3_c64_wgrad_scratch_floats(), device=dev)
+    ops.conv3_c64_wgrad(dyd, xd, dw, db, scr, B, H, W)
+    assert ((dw.cpu().double() - 0.5) - w64.grad).abs().max().item() <= 2e-4 * w64.grad.abs().max().item() + 1e-4
+    assert ((db.cpu().double() + 0.25) - b64.grad).abs().max().item() <= 2e-4 * b64.grad.abs().max().item() + 1e-4
+    dw2 = torch.zeros_like(dw)
+    ops.conv3_c64_wgrad(dyd, xd, dw2, None, scr, B, H, W)
+    dw3 = torch.zeros_like(dw)
+    ops.conv3_c64_wgrad(dyd, xd, dw3, None, scr, B, H, W)
+    assert torch.equal(dw2, dw3)
+
+
+def test_body_convolution_many_tiles_vs_gemm_path(ops):
+    """1 x 512 x 1024 (1,024 / 2,048 tiles: every persistent workgroup walks several) against the K-segment GEMMs the kernels replace."""
+    dev = torch.device("cuda:0")
+    B, H, W = 1, 512, 1024
+    M = B * H * W
+    g = torch.Generator().manual_seed(5)
+    xd = torch.randn(M, 64, generator=g).bfloat16().to(dev)
+    dyd = torch.randn(M, 64, generator=g).bfloat16().to(dev)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.04).bfloat16()
+    wg = w.permute(0, 2, 3, 1).reshape(64, 576).contiguous().to(dev)
+    bd = (torch.randn(64, generator=g) * 0.1).to(dev)
+    taps = [(a, c) for a in (-1, 0, 1) for c in (-1, 0, 1)]
+    segs = [ops.SegSpec(xd, 64, 0, a, c, 1, 0, H, W) for (a, c) in taps]
+    y, y_g = torch.empty(M, 64, device=dev, dtype=torch.bfloat16), torch.empty(M, 64, device=dev, dtype=torch.bfloat16)
+    ops.conv3_c64_fwd(xd, wg, y, B, H, W, bias=bd, relu=True)
+    ops.gemm_nt(segs, wg, y_g, M, 64, 576, spatial=(H, W), bias=bd, relu=True)
+    assert (y.float() - y_g.float()).norm().item() <= 3e-3 * y_g.float().norm().item()
+    scr = torch.empty(ops.conv3_c64_wgrad_scratch_floats(), device=dev)
+    dw, db = torch.zeros(64, 64, 3, 3, device=dev), torch.zeros(64, device=dev)
+    ops.conv3_c64_wgrad(dyd, xd, dw, db, scr, B, H, W)
+    dw_g, db_g = torch.zeros(64, 576, device=dev), torch.zeros(64, device=dev)
+    ops.gemm_tn(dyd, segs, dw_g, M, 64, 576, spatial=(H, W), dbias=db_g, kperm=(64, 9))
+    assert (dw - dw_g.view(64, 64, 3, 3)).abs().max().item() <= 1e-3 * dw_g.abs().max().item()
+    assert (db - db_g).abs().max().item() <= 1e-3 * db_g.abs().max().item()
+
+
 def test_rejects_float32_and_misaligned(ops):
     dev = torch.device("cuda:0")
     x = torch.zeros(64, 64, device=dev)
