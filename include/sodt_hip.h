@@ -178,18 +178,29 @@ int sodt_conv3x3_c64n8_wgrad(const void* dy, const void* x, float* dw, float* db
                              sodt_stream_t st);
 long sodt_conv3x3_c64n8_wgrad_scratch_bytes(void);
 
-/* ---- the 3x3 convolutions of EDSR's body at 64 -> 64 channels (edsr.py:34-53 ResBlock: conv -> ReLU -> conv, + x; :64-70 head and
- * body-closing convolutions), token-major rows, bf16 only (csrc/conv3.hip): the input tile crosses the CU once, the weights live in registers.
+/* ---- the 3x3 convolutions of EDSR at 64 input channels and 64 output channels per launch (edsr.py:34-53 ResBlock: conv -> ReLU -> conv,
+ * + x; :64-70 head and body-closing convolutions; :14-24 Upsampler: conv(64 -> 256) + nn.PixelShuffle(2) as four launches), token-major
+ * rows, bf16 only (csrc/conv3.hip): the input tile crosses the CU once, the weights live in registers.
  *   sodt_conv3x3_c64_fwd: y [B*H*W][64] = epilogue(x [B*H*W][64] (*) w); w [64][9*64] = [n][tap*64 + c].  flip != 0 mirrors the taps
  *     (tap' = 8 - tap): with w = the transposed weights [c][tap*64 + n] and x = dy this is the input gradient.  flags: any of
- *     SODT_EPI_BIAS (bias f32[64]), SODT_EPI_RELU, SODT_EPI_DRELU (aux [B*H*W][64]: keep where aux > 0), SODT_EPI_RESID (resid
- *     [B*H*W][64]), applied in that order as in sodt_gemm_nt; anything else is SODT_EINVAL.
+ *     SODT_EPI_BIAS (bias f32), SODT_EPI_RELU, and ONE of SODT_EPI_DRELU (aux [B*H*W][64]: keep where aux > 0) / SODT_EPI_RESID (resid
+ *     [B*H*W][64]; may be y itself), applied in that order as in sodt_gemm_nt; anything else is SODT_EINVAL.
  *   sodt_conv3x3_c64_wgrad: dw [64][64][3][3] (torch layout) += dy^T x(taps), db [64] += column sums of dy (or NULL); scratch:
- *     sodt_conv3x3_c64_wgrad_scratch_bytes() bytes (per-workgroup partials, summed in a fixed order by a second launch). */
+ *     sodt_conv3x3_c64_wgrad_scratch_bytes() bytes (per-workgroup partials, summed in a fixed order by a second launch).
+ *   geo (NULL = identity): H x W is the grid the kernel walks.  Output channel n uses weight / bias (and dw / db) row
+ *     w_row_stride * n + w_row_off; the input pixel (y, x) is read at (in_mul y + in_i, in_mul x + in_j) of an (in_mul H) x (in_mul W)
+ *     tensor; the output pixel - and the epilogue operand, and dy of the weight gradient - at (out_mul y + out_i, out_mul x + out_j) of
+ *     an (out_mul H) x (out_mul W) tensor; in_mul, out_mul in {1, 2}.  PixelShuffle(2) of a 64 -> 256 convolution = four launches with
+ *     (w_row_stride, w_row_off, out_mul, out_i, out_j) = (4, 2 i + j, 2, i, j); its gradients read the fine gradient through the same map. */
+typedef struct {
+  int w_row_stride, w_row_off;
+  int in_mul, in_i, in_j;
+  int out_mul, out_i, out_j;
+} sodt_conv3_geo;
 int sodt_conv3x3_c64_fwd(const void* x, const void* w, const float* bias, const void* resid, const void* aux, void* y, int B, int H, int W,
-                         int flags, int flip, int dtype, sodt_stream_t st);
-int sodt_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, int dtype,
-                           sodt_stream_t st);
+                         int flags, int flip, const sodt_conv3_geo* geo, int dtype, sodt_stream_t st);
+int sodt_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, const sodt_conv3_geo* geo,
+                           int dtype, sodt_stream_t st);
 long sodt_conv3x3_c64_wgrad_scratch_bytes(void);
 
 /* ---- fused W-MSA / SW-MSA half of a Swin block (csrc/wmsa_block.hip) -------------------------------------------

@@ -75,6 +75,12 @@ class PrepDesc(C.Structure):
 
 # name -> argtypes (all return int except sodt_version)
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+class Conv3Geo(C.Structure):
+    """sodt_conv3_geo (include/sodt_hip.h): weight-row / input-pixel / output-pixel maps of the direct 3x3 kernels."""
+    _fields_ = [("w_row_stride", C.c_int), ("w_row_off", C.c_int), ("in_mul", C.c_int), ("in_i", C.c_int), ("in_j", C.c_int),
+                ("out_mul", C.c_int), ("out_i", C.c_int), ("out_j", C.c_int)]
+
+
 SIGNATURES = {
     "sodt_nms_candidates": [_P, _I, _I, C.c_float, _I, _P, _P, _I, _P, _P],
     "sodt_nms_workspace_bytes": [_L, C.POINTER(C.c_size_t)],
@@ -131,8 +137,8 @@ SIGNATURES = {
     "sodt_conv3x3_c64n8_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sodt_conv3x3_c64n8_dgrad": [_P, _P, _P, _I, _I, _I, _I, _P],
     "sodt_conv3x3_c64n8_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "sodt_conv3x3_c64_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "sodt_conv3x3_c64_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sodt_conv3x3_c64_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
+    "sodt_conv3x3_c64_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P],
     "sodt_debug_wmsa_stamps": [_P, _I],
     "sodt_debug_wmsa_hg_stamps": [_P, _I],
 }

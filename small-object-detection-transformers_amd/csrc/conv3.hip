@@ -349,9 +349,14 @@ __global__ __launch_bounds__(256) void conv3_n8_wgrad_reduce_kernel(const float*
 // take a second, predicated instantiation): hipcc then counts vmcnt exactly, so the epilogue operands that are fetched four rows ahead
 // and the next tile's chunks stay in flight across the rows - with a predicated load anywhere in the loop it falls back to vmcnt(0)
 // before every row and the wave eats a memory latency sixteen times per tile.
+// Geometry maps (sodt_conv3_geo, include/sodt_hip.h): the input pixel (y, x) of the H x W grid the kernel walks may live at
+// (im y + ii, im x + ij) of an (im H) x (im W) tensor, the output pixel likewise (om, oi, oj), and output channel n may take weight /
+// bias row wrs n + wro.  With (4, 2 i + j) and om = 2 a 64 -> 256 convolution + nn.PixelShuffle(2) (edsr.py:19-24) is four launches that
+// write the shuffled tensor directly; with im = 2 the four planes of the fine gradient are read in place (no inverse shuffle).
 struct C64Args {
   const bf16* x; const bf16* w; const float* bias; const bf16* resid; const bf16* aux; bf16* y;
   int flags, flip;
+  int wrs, wro, im, ii, ij, om, oi, oj;
 };
 
 __device__ __attribute__((aligned(16))) unsigned int c3_zero16[4] = {0u, 0u, 0u, 0u};
@@ -368,14 +373,16 @@ __device__ __forceinline__ void c64_rows(const C64Args& a, const Tiles& t, const
                                          const f32x4 binit, int b, int y0, int x0, int n0, int h, int fr) {
   const bool relu = a.flags & SODT_EPI_RELU, drelu = HAS_E && (a.flags & SODT_EPI_DRELU), res = HAS_E && (a.flags & SODT_EPI_RESID);
   const bf16* eop = drelu ? a.aux : a.resid;         // (at most one of the two: checked by the entry point)
-  const long tb = (((long)b * t.H + y0) * t.W + x0 + 16 * h) * 64 + n0;
+  const int oW = a.om * t.W;                          // output row pitch in pixels
+  const long tb = (((long)b * a.om * t.H + a.om * y0 + a.oi) * oW + a.om * (x0 + 16 * h) + a.oj) * 64 + n0;
+  const unsigned ofr = (unsigned)(fr * a.om * 64), orow = (unsigned)(a.om * oW * 64);
   const bool colok = FULL || x0 + 16 * h + fr < t.W;
   uint2 re[4];
   auto ldrow = [&](int row, uint2& q) {
     if (!HAS_E) return;
     // FULL: no predicated access anywhere in the loop (hipcc then counts vmcnt exactly and the loads stay in flight across rows)
     const bool ok = FULL || (colok && y0 + row < t.H);
-    q = ok ? *(const uint2*)(eop + tb + (unsigned)((row * t.W + fr) * 64)) : make_uint2(0u, 0u);
+    q = ok ? *(const uint2*)(eop + tb + (row * orow + ofr)) : make_uint2(0u, 0u);
   };
 #pragma unroll
   for (int jr = 0; jr < 4; ++jr) ldrow(jr, re[jr]);
@@ -433,7 +440,7 @@ __device__ __forceinline__ void c64_rows(const C64Args& a, const Tiles& t, const
           v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xffff0000u);
           v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xffff0000u);
         }
-        *(uint2*)(a.y + tb + (unsigned)((oy * t.W + fr) * 64)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        *(uint2*)(a.y + tb + (oy * orow + ofr)) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
       }
       if (oy + 4 < C_TH) ldrow(oy + 4, re[jr]);
     }
@@ -447,22 +454,26 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_kernel(const C64Args a, cons
 #pragma unroll
   for (int ks = 0; ks < 18; ++ks) {
     const int tp = ks >> 1, col = (a.flip ? 8 - tp : tp) * 64 + (ks & 1) * 32 + 8 * fg;
-    wf[ks] = *(const uint4*)(a.w + (16 * wv + fr) * 576 + col);
+    wf[ks] = *(const uint4*)(a.w + (long)(a.wrs * (16 * wv + fr) + a.wro) * 576 + col);
   }
   const int n0 = 16 * wv + 4 * fg;
   f32x4 binit = {0.f, 0.f, 0.f, 0.f};
-  if (a.flags & SODT_EPI_BIAS) binit = *(const f32x4*)(a.bias + n0);
+  if (a.flags & SODT_EPI_BIAS) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) binit[r] = a.bias[a.wrs * (n0 + r) + a.wro];
+  }
   uint32_t off[3][2];
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
     for (int hk = 0; hk < 2; ++hk) off[kx][hk] = (fr + kx) * 128 + ((((hk << 2) | fg) ^ ((fr + kx) & 7)) << 4);
+  const int iW = a.im * t.W;
 
   uint4 pf[C_R];
   auto issue = [&](long tl) {
     int b, y0, x0;
     tile_origin(t, tl, b, y0, x0);
-    const char* xb = (const char*)a.x + (((long)b * t.H + (y0 - 1)) * t.W + (x0 - 1)) * 128;
+    const char* xb = (const char*)a.x + (((long)b * a.im * t.H + a.im * (y0 - 1) + a.ii) * iW + a.im * (x0 - 1) + a.ij) * 128;
     int tz = tid; asm volatile("" : "+v"(tz));
 #pragma unroll
     for (int r = 0; r < C_R; ++r) {
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_kernel(const C64Args a, cons
       const int py = pix / CPX, px = pix - py * CPX;
       const int gy = y0 - 1 + py, gx = x0 - 1 + px;
       const bool ok = i < C_CH && (unsigned)gy < (unsigned)t.H && (unsigned)gx < (unsigned)t.W;
-      pf[r] = ok ? *(const uint4*)(xb + (unsigned)((py * t.W + px) * 128 + ch * 16)) : make_uint4(0u, 0u, 0u, 0u);
+      pf[r] = ok ? *(const uint4*)(xb + (unsigned)((py * iW + px) * a.im * 128 + ch * 16)) : make_uint4(0u, 0u, 0u, 0u);
     }
   };
   auto stash = [&]() {
@@ -511,7 +522,7 @@ constexpr int G_TH = 8, G_XCH = (G_TH + 2) * CPX * 8, G_XR = (G_XCH + 511) / 512
 constexpr int G_PART = 64 * 577;
 
 __global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, float* __restrict__ part,
-                                                                const Tiles t) {
+                                                                const Tiles t, const int dm, const int di, const int dj) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[(G_TH + 2) * CPX * 128];     // x halo tile
   __shared__ __attribute__((aligned(16))) unsigned char gt[G_TH * TW * 128];              // dy tile (chunks swizzled with the pixel's column)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wv = wave & 3, par = wave >> 2, fr = lane & 15, fg = lane >> 4;
@@ -526,7 +537,8 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_kernel(const bf16* __r
     int b, y0, x0;
     tile_origin(t, tl, b, y0, x0);
     const char* xb = (const char*)x + (((long)b * t.H + (y0 - 1)) * t.W + (x0 - 1)) * 128;
-    const char* gb = (const char*)dy + (((long)b * t.H + y0) * t.W + x0) * 128;
+    const int dW = dm * t.W;                            // dy pixel (y, x) lives at (dm y + di, dm x + dj) of a (dm H) x (dm W) tensor
+    const char* gb = (const char*)dy + (((long)b * dm * t.H + dm * y0 + di) * dW + dm * x0 + dj) * 128;
     int tz = tid; asm volatile("" : "+v"(tz));
 #pragma unroll
     for (int r = 0; r < G_XR; ++r) {
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_kernel(const bf16* __r
       const int i = tz + 512 * r, pix = i >> 3, ch = i & 7;
       const int py = pix >> 5, px = pix & 31;
       const bool ok = y0 + py < t.H && x0 + px < t.W;
-      pg[r] = ok ? *(const uint4*)(gb + (unsigned)((py * t.W + px) * 128 + ch * 16)) : make_uint4(0u, 0u, 0u, 0u);
+      pg[r] = ok ? *(const uint4*)(gb + (unsigned)((py * dW + px) * dm * 128 + ch * 16)) : make_uint4(0u, 0u, 0u, 0u);
     }
   };
   long cur = tile_of(t, 0);
@@ -604,7 +616,8 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_kernel(const bf16* __r
 
 // dw += the sum of the partials in a fixed order: a block owns 64 consecutive entries, its four waves take every fourth partial (256-byte
 // row reads), LDS adds the four sums
-__global__ __launch_bounds__(256) void conv3_c64_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw, float* __restrict__ db) {
+__global__ __launch_bounds__(256) void conv3_c64_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw, float* __restrict__ db,
+                                                                   int wrs, int wro) {
   __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
@@ -622,10 +635,16 @@ __global__ __launch_bounds__(256) void conv3_c64_wgrad_reduce_kernel(const float
   __syncthreads();
   if (g == 0 && i < G_PART) {
     s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
-    const int n = i / 577, k = i - n * 577;
-    if (k < 576) dw[(n * 64 + (k & 63)) * 9 + (k >> 6)] += s;
+    const int n = wrs * (i / 577) + wro, k = i % 577;
+    if (k < 576) dw[((long)n * 64 + (k & 63)) * 9 + (k >> 6)] += s;
     else if (db) db[n] += s;
   }
+}
+
+inline bool geo_ok(const sodt_conv3_geo* g) {
+  return !g || (g->w_row_stride >= 1 && g->w_row_off >= 0 && g->w_row_off < g->w_row_stride && g->in_mul >= 1 && g->out_mul >= 1 &&
+                g->in_i >= 0 && g->in_i < g->in_mul && g->in_j >= 0 && g->in_j < g->in_mul && g->out_i >= 0 && g->out_i < g->out_mul &&
+                g->out_j >= 0 && g->out_j < g->out_mul && g->in_mul <= 2 && g->out_mul <= 2);
 }
 
 inline bool ok_common(const void* a, const void* b, const void* c, int B, int H, int W, int dtype) {
@@ -663,14 +682,18 @@ int sodt_conv3x3_c64n8_wgrad(const void* dy, const void* x, float* dw, float* db
 }
 
 int sodt_conv3x3_c64_fwd(const void* x, const void* w, const float* bias, const void* resid, const void* aux, void* y, int B, int H, int W,
-                         int flags, int flip, int dtype, hipStream_t st) {
-  if (!ok_common(x, w, y, B, H, W, dtype) || ((((uintptr_t)bias) | ((uintptr_t)resid) | ((uintptr_t)aux)) & 15)) return SODT_EINVAL;
+                         int flags, int flip, const sodt_conv3_geo* geo, int dtype, hipStream_t st) {
+  if (!ok_common(x, w, y, B, H, W, dtype) || ((((uintptr_t)bias) | ((uintptr_t)resid) | ((uintptr_t)aux)) & 15) || !geo_ok(geo)) return SODT_EINVAL;
   if (flags & ~(SODT_EPI_BIAS | SODT_EPI_RELU | SODT_EPI_DRELU | SODT_EPI_RESID)) return SODT_EINVAL;
   if (((flags & SODT_EPI_BIAS) && !bias) || ((flags & SODT_EPI_RESID) && !resid) || ((flags & SODT_EPI_DRELU) && !aux)) return SODT_EINVAL;
   if ((flags & SODT_EPI_RESID) && (flags & SODT_EPI_DRELU)) return SODT_EINVAL;       // one epilogue operand per launch (no layer of the branch has both)
   C64Args a;
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = bias; a.resid = (const bf16*)resid; a.aux = (const bf16*)aux; a.y = (bf16*)y;
   a.flags = flags; a.flip = flip ? 1 : 0;
+  a.wrs = geo ? geo->w_row_stride : 1; a.wro = geo ? geo->w_row_off : 0;
+  a.im = geo ? geo->in_mul : 1; a.ii = geo ? geo->in_i : 0; a.ij = geo ? geo->in_j : 0;
+  a.om = geo ? geo->out_mul : 1; a.oi = geo ? geo->out_i : 0; a.oj = geo ? geo->out_j : 0;
+  if ((long)B * H * W * a.im * a.im >= (1L << 31) || (long)B * H * W * a.om * a.om >= (1L << 31)) return SODT_EINVAL;
   const Tiles t = make_tiles(B, H, W, C_TH);
   const int grid = (int)(t.ntiles < GRID / 2 ? ((t.ntiles + 7) / 8) * 8 : GRID / 2);       // one 8-wave workgroup per CU
   hipLaunchKernelGGL(conv3_c64_kernel, dim3(grid), dim3(512), 0, st, a, t);
@@ -679,12 +702,18 @@ int sodt_conv3x3_c64_fwd(const void* x, const void* w, const float* bias, const 
 
 long sodt_conv3x3_c64_wgrad_scratch_bytes(void) { return (long)(GRID / 2) * 2 * G_PART * 4; }
 
-int sodt_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, int dtype, hipStream_t st) {
-  if (!ok_common(dy, x, scratch, B, H, W, dtype) || !dw) return SODT_EINVAL;
+int sodt_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, const sodt_conv3_geo* geo,
+                           int dtype, hipStream_t st) {
+  if (!ok_common(dy, x, scratch, B, H, W, dtype) || !dw || !geo_ok(geo)) return SODT_EINVAL;
+  if (geo && geo->in_mul != 1) return SODT_EINVAL;                       // (x is always on the walked grid; dy uses the out_* map)
+  const int dm = geo ? geo->out_mul : 1;
+  if ((long)B * H * W * dm * dm >= (1L << 31)) return SODT_EINVAL;
   const Tiles t = make_tiles(B, H, W, G_TH);
   const int grid = (int)(t.ntiles < GRID / 2 ? ((t.ntiles + 7) / 8) * 8 : GRID / 2);       // one 8-wave workgroup per CU
-  hipLaunchKernelGGL(conv3_c64_wgrad_kernel, dim3(grid), dim3(512), 0, st, (const bf16*)dy, (const bf16*)x, scratch, t);
-  hipLaunchKernelGGL(conv3_c64_wgrad_reduce_kernel, dim3((G_PART + 63) / 64), dim3(256), 0, st, (const float*)scratch, 2 * grid, dw, db);
+  hipLaunchKernelGGL(conv3_c64_wgrad_kernel, dim3(grid), dim3(512), 0, st, (const bf16*)dy, (const bf16*)x, scratch, t, dm, geo ? geo->out_i : 0,
+                     geo ? geo->out_j : 0);
+  hipLaunchKernelGGL(conv3_c64_wgrad_reduce_kernel, dim3((G_PART + 63) / 64), dim3(256), 0, st, (const float*)scratch, 2 * grid, dw, db,
+                     geo ? geo->w_row_stride : 1, geo ? geo->w_row_off : 0);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 

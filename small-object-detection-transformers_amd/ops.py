@@ -381,23 +381,33 @@ def conv3_n8_wgrad(dy, x, dw, db, scratch, B, H, W, cout):
     _launch("sodt_conv3x3_c64n8_wgrad", dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _p(db), scratch.data_ptr(), B, H, W, cout, dt_code(dy))
 
 
-def conv3_c64_fwd(x, w, y, B, H, W, bias=None, relu=False, drelu_aux=None, resid=None, flip=False):
+def conv3_geo(w_row=(1, 0), inp=(1, 0, 0), out=(1, 0, 0)):
+    """sodt_conv3_geo: output channel n <-> weight row w_row[0] * n + w_row[1]; input / output pixel (y, x) <-> (m y + i, m x + j)."""
+    g = L.Conv3Geo()
+    g.w_row_stride, g.w_row_off = w_row
+    g.in_mul, g.in_i, g.in_j = inp
+    g.out_mul, g.out_i, g.out_j = out
+    return g
+
+
+def conv3_c64_fwd(x, w, y, B, H, W, bias=None, relu=False, drelu_aux=None, resid=None, flip=False, geo=None):
     """y [B*H*W][64] = epilogue(conv3x3(x [B*H*W][64]; w [64][576] = [n][tap*64 + c])), bf16 (csrc/conv3.hip); flip: mirrored taps (the
-    input gradient with the transposed weights)."""
+    input gradient with the transposed weights); geo: conv3_geo(...) maps (H x W is the grid the kernel walks)."""
     flags = ((L.EPI_BIAS if bias is not None else 0) | (L.EPI_RELU if relu else 0) | (L.EPI_DRELU if drelu_aux is not None else 0)
              | (L.EPI_RESID if resid is not None else 0))
     _launch("sodt_conv3x3_c64_fwd", x.data_ptr(), w.data_ptr(), _p(bias), _p(resid), _p(drelu_aux), y.data_ptr(), B, H, W, flags,
-            int(bool(flip)), dt_code(x))
+            int(bool(flip)), C.byref(geo) if geo is not None else None, dt_code(x))
 
 
 def conv3_c64_wgrad_scratch_floats() -> int:
     return int(_lib.sodt_conv3x3_c64_wgrad_scratch_bytes()) // 4
 
 
-def conv3_c64_wgrad(dy, x, dw, db, scratch, B, H, W):
-    """dw [64][64][3][3] f32 +=, db [64] f32 += (or None), bf16 operands."""
+def conv3_c64_wgrad(dy, x, dw, db, scratch, B, H, W, geo=None):
+    """dw [..][64][3][3] f32 +=, db f32 += (or None), bf16 operands; geo: dy through the out_* map, dw / db rows through w_row."""
     assert dw.dtype == torch.float32 and dw.is_contiguous() and scratch.dtype == torch.float32
-    _launch("sodt_conv3x3_c64_wgrad", dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _p(db), scratch.data_ptr(), B, H, W, dt_code(dy))
+    _launch("sodt_conv3x3_c64_wgrad", dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _p(db), scratch.data_ptr(), B, H, W,
+            C.byref(geo) if geo is not None else None, dt_code(dy))
 
 
 def add_rows(dst, src, M, Cc, ldd=None, dcol=0, lds=None, scol=0):

@@ -96,7 +96,7 @@ class _Conv:
     """GEMM views of one Conv2d: w [Np][taps*Cin] (forward), wT [Cin][taps*Np] (input gradient) in the run dtype; Np = Cout rounded
     up to 8 (zero rows / columns: the closing 64 -> ch convolution has 3 or 4 outputs).  The forward GEMM runs at N = Cout over the
     padded rows, as Detect's does (engine.py: det_np)."""
-    __slots__ = ("name", "cout", "cin", "k", "taps", "np_", "w", "wT", "bias", "dw_pad", "db_pad", "bias_pad")
+    __slots__ = ("name", "cout", "cin", "k", "taps", "np_", "w", "wT", "bias", "dw_pad", "db_pad", "bias_pad", "wTp")
 
 
 class SRBranch:
@@ -137,6 +137,12 @@ class SRBranch:
                 descs.append(self._desc(v, c.w, (c.cout, c.cin, c.taps), (0, 2, 1), c.taps * c.cin, 0))
             c.wT = torch.zeros(c.cin, c.taps * c.np_, device=self.dev, dtype=dt)                      # [c][tap*Np + n]
             descs.append(self._desc(v, c.wT, (c.cout, c.cin, c.taps), (1, 2, 0), c.taps * c.np_, c.np_ if c.np_ != c.cout else 0))
+            # Upsampler stage (64 -> 256 + PixelShuffle 2, edsr.py:14-24) on the direct kernels: the input gradient of plane p = 2 i + j
+            # wants wTp[p][k][tap * 64 + c] = W[4 c + p][k][tap] - the plain transpose of W viewed as [64 (c)][4 * 576 (p, k, tap)]
+            c.wTp = None
+            if dt == torch.bfloat16 and c.k == 3 and c.cin == 64 and c.cout == 256:
+                c.wTp = torch.zeros(4, 64, 576, device=self.dev, dtype=dt)
+                descs.append(self._desc(v, c.wTp, (64, 4 * 576, 1), (1, 2, 0), 64, 0))
             self.c[c.name] = c
         arr = (L.PrepDesc * len(descs))(*descs)
         self._tab = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev), len(descs),
@@ -327,10 +333,18 @@ class SRBranch:
         self.f_t = []
         j = 0
         while f"{e}tail.0.{2 * j}" in c:
-            z = self._buf(f"e.z{j}", (B * gh * gw, 256))
-            fj = self._conv(f"{e}tail.0.{2 * j}", [SegSpec(cur)], gh, gw, B * gh * gw, z)
+            cj = c[f"{e}tail.0.{2 * j}"]
             pj = self._buf(f"e.p{j}", (B * 4 * gh * gw, 64))
-            ops.pixel_shuffle2(z, pj, B, gh, gw, 64)
+            if cj.wTp is not None:
+                # conv(64 -> 256) + PixelShuffle(2): plane p = 2 i + j (output channels 4 c + p) is a 64 -> 64 convolution whose pixel
+                # (y, x) is stored at (2 y + i, 2 x + j) of the shuffled tensor - no 256-channel tensor, no shuffle launch
+                for pl in range(4):
+                    ops.conv3_c64_fwd(cur, cj.w, pj, B, gh, gw, bias=cj.bias, geo=ops.conv3_geo(w_row=(4, pl), out=(2, pl >> 1, pl & 1)))
+                fj = ("direct", cur)
+            else:
+                z = self._buf(f"e.z{j}", (B * gh * gw, 256))
+                fj = self._conv(f"{e}tail.0.{2 * j}", [SegSpec(cur)], gh, gw, B * gh * gw, z)
+                ops.pixel_shuffle2(z, pj, B, gh, gw, 64)
             self.f_t.append((fj, gh, gw))
             cur, gh, gw = pj, 2 * gh, 2 * gw
             j += 1
@@ -356,10 +370,21 @@ class SRBranch:
         self._conv_bwd(e + "tail.1", do, ct.np_, self.f_o, gh, gw, B * gh * gw, dcur)
         for j in reversed(range(nt)):
             fj, hj, wj = self.f_t[j]
-            dz = self._buf(f"g.z{j}", (B * hj * wj, 256))
-            ops.pixel_shuffle2(dcur, dz, B, hj, wj, 64, inverse=True)
             dsrc = self._buf(f"g.p{j}", (B * hj * wj, 64))
-            self._conv_bwd(f"{e}tail.0.{2 * j}", dz, 256, fj, hj, wj, B * hj * wj, dsrc)
+            if fj[0] == "direct":
+                # the four planes of the fine gradient are read in place: weight / bias gradient rows 4 c + p, and the input gradient
+                # summed over the planes (launch p adds to what launches < p stored: the residual operand is the output itself)
+                name, cj = f"{e}tail.0.{2 * j}", c[f"{e}tail.0.{2 * j}"]
+                scr = self._buf("c64.scratch", (ops.conv3_c64_wgrad_scratch_floats(),), torch.float32)
+                for pl in range(4):
+                    ops.conv3_c64_wgrad(dcur, fj[1], self.g[name + ".weight"], self.g[name + ".bias"], scr, B, hj, wj,
+                                        geo=ops.conv3_geo(w_row=(4, pl), out=(2, pl >> 1, pl & 1)))
+                    ops.conv3_c64_fwd(dcur, cj.wTp[pl], dsrc, B, hj, wj, flip=True, resid=dsrc if pl else None,
+                                      geo=ops.conv3_geo(inp=(2, pl >> 1, pl & 1)))
+            else:
+                dz = self._buf(f"g.z{j}", (B * hj * wj, 256))
+                ops.pixel_shuffle2(dcur, dz, B, hj, wj, 64, inverse=True)
+                self._conv_bwd(f"{e}tail.0.{2 * j}", dz, 256, fj, hj, wj, B * hj * wj, dsrc)
             dcur = dsrc
         d_rb = dcur            # d(closing-conv output + head output): the head receives it directly and through the residual chain
         dr = self._buf("g.r", (M1, 64))

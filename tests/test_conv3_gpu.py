@@ -216,6 +216,49 @@ def test_body_convolution_many_tiles_vs_gemm_path(ops):
     assert (db - db_g).abs().max().item() <= 1e-3 * db_g.abs().max().item()
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 12, 40), (1, 40, 72)])
+def test_upsampler_stage_conv_256_plus_pixel_shuffle_as_four_plane_launches(ops, B, H, W):
+    """edsr.py:14-24: conv(64 -> 256, 3) + nn.PixelShuffle(2).  Plane p = 2 i + j (output channels 4 c + p) is a 64 -> 64 launch that stores
+    pixel (y, x) at (2 y + i, 2 x + j); the gradients read the fine gradient through the same map (sodt_conv3_geo).  Against float64
+    F.conv2d + F.pixel_shuffle autograd on the same bf16 operands."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H + 3 * W)
+    M = B * H * W
+    x = torch.randn(B, H, W, 64, generator=g).bfloat16()
+    w = (torch.randn(256, 64, 3, 3, generator=g) * 0.04).bfloat16()
+    b = torch.randn(256, generator=g) * 0.1
+    dfine = torch.randn(B, 2 * H, 2 * W, 64, generator=g).bfloat16()
+    x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    ref = F.pixel_shuffle(F.conv2d(x64, w64, b64, padding=1), 2)                 # (B, 64, 2H, 2W)
+    ref.backward(dfine.double().permute(0, 3, 1, 2))
+    refr = ref.detach().permute(0, 2, 3, 1)
+    xd, bd = x.reshape(M, 64).to(dev), b.to(dev)
+    wg = w.permute(0, 2, 3, 1).reshape(256, 576).contiguous().to(dev)            # [n][tap * 64 + c]
+    wTp = w.reshape(64, 4 * 576).t().contiguous().view(4, 64, 576).to(dev)      # [p][k][tap * 64 + c] = W[4 c + p][k][tap]
+    y = torch.full((4 * M, 64), 9.0, device=dev, dtype=torch.bfloat16)
+    for p in range(4):
+        ops.conv3_c64_fwd(xd, wg, y, B, H, W, bias=bd, geo=ops.conv3_geo(w_row=(4, p), out=(2, p >> 1, p & 1)))
+    got = y.float().cpu().view(B, 2 * H, 2 * W, 64).double()
+    assert (got - refr).norm().item() <= 2.5e-3 * refr.norm().item()
+    assert (got - refr).abs().max().item() <= 8e-3 * refr.abs().max().item()
+
+    dd = dfine.reshape(4 * M, 64).to(dev)
+    dx = torch.full((M, 64), 5.0, device=dev, dtype=torch.bfloat16)
+    dw, db = torch.full((256, 64, 3, 3), 0.5, device=dev), torch.full((256,), -0.25, device=dev)
+    scr = torch.empty(ops.conv3_c64_wgrad_scratch_floats(), device=dev)
+    for p in range(4):
+        ops.conv3_c64_wgrad(dd, xd, dw, db, scr, B, H, W, geo=ops.conv3_geo(w_row=(4, p), out=(2, p >> 1, p & 1)))
+        ops.conv3_c64_fwd(dd, wTp[p], dx, B, H, W, flip=True, resid=dx if p else None, geo=ops.conv3_geo(inp=(2, p >> 1, p & 1)))
+    rdx = x64.grad.permute(0, 2, 3, 1)
+    gdx = dx.float().cpu().view(B, H, W, 64).double()
+    # (three bf16 roundings of the running sum on top of the output rounding)
+    assert (gdx - rdx).norm().item() <= 5e-3 * rdx.norm().item()
+    assert ((dw.cpu().double() - 0.5) - w64.grad).abs().max().item() <= 2e-4 * w64.grad.abs().max().item() + 1e-4
+    assert ((db.cpu().double() + 0.25) - b64.grad).abs().max().item() <= 2e-4 * b64.grad.abs().max().item() + 1e-4
+
+
 def test_rejects_float32_and_misaligned(ops):
     dev = torch.device("cuda:0")
     x = torch.zeros(64, 64, device=dev)
