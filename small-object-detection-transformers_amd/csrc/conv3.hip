@@ -515,9 +515,13 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_kernel(const C64Args a, cons
   }
 }
 
-// weight gradient, 64 -> 64: dW[n][tap][c] = sum_p dy[p][n] x[p + tap][c].  Eight waves: wave (w = n-tile, e = strip parity) keeps the 36 + 1
-// accumulator tiles of its 16 output channels; both operands come from LDS through the transposing read, every wave reads every x
-// fragment of its strips.  One partial [64][577] per (workgroup, parity), summed by the reduce launch.
+// weight gradient, 64 -> 64: dW[n][tap][c] = sum_p dy[p][n] x[p + tap][c], pixels as the MFMA contraction index, both operands from LDS
+// through the transposing read.  Eight waves: wave (w, e) keeps the accumulator tiles of output channels 16 w .. 16 w + 15 x input
+// channels 32 e .. 32 e + 31 for all nine taps (18 tiles + 1 against a vector of ones: the bias gradient) and SLIDES down the ten halo
+// rows of x like the forward kernel: the six x fragments of halo row r (three tap columns x two channel tiles) meet the dy fragments
+// of rows r, r - 1, r - 2 (tap rows 0, 1, 2; a rolling window), so an x fragment is read once per tile, not once per tap row.
+// The next row's fragments are read behind this row's MFMAs (sched_group_barrier / sched_barrier as in c64_rows).  One partial
+// [64][577] per workgroup, summed by the reduce launch.
 constexpr int G_TH = 8, G_XCH = (G_TH + 2) * CPX * 8, G_XR = (G_XCH + 511) / 512, G_YCH = G_TH * TW * 8, G_YR = G_YCH / 512;   // 2720 / 6, 2048 / 4
 constexpr int G_PART = 64 * 577;
 
@@ -525,12 +529,12 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_kernel(const bf16* __r
                                                                 const Tiles t, const int dm, const int di, const int dj) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[(G_TH + 2) * CPX * 128];     // x halo tile
   __shared__ __attribute__((aligned(16))) unsigned char gt[G_TH * TW * 128];              // dy tile (chunks swizzled with the pixel's column)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wv = wave & 3, par = wave >> 2, fr = lane & 15, fg = lane >> 4;
-  f32x4 acc[9][4], accb = {0.f, 0.f, 0.f, 0.f};
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wv = wave & 3, ce = wave >> 2, fr = lane & 15, fg = lane >> 4;
+  f32x4 acc[9][2], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[tp][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c2 = 0; c2 < 2; ++c2) acc[tp][c2] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
   uint4 pf[G_XR], pg[G_YR];
   auto issue = [&](long tl) {
@@ -577,39 +581,61 @@ __global__ __launch_bounds__(512, 2) void conv3_c64_wgrad_kernel(const bf16* __r
     }
     __syncthreads();
     if (nxt >= 0) issue(nxt);
-#pragma unroll 1
-    for (int s = 0; s < G_TH / 2; ++s) {
-      const int oy = 2 * s + par;
-      int lz = lane; asm volatile("" : "+v"(lz));          // (lane-derived offsets re-derived per strip: as loop invariants they are spilled)
-      const int p = lz & 3, ox = (lz >> 4) * 4 + ((lz & 15) >> 2);   // this lane's row segment: strip pixel ox (and ox + 16: same & 7)
-      const uint4 ga = tr_frag(gt + (oy * TW + ox) * 128 + (((2 * wv + (p >> 1)) ^ (ox & 7)) << 4) + (p & 1) * 8, 16 * 128);
-      mma16<bf16>(accb, ga, ones);
+    int lz = lane; asm volatile("" : "+v"(lz));          // (lane-derived offsets re-derived per tile: as loop invariants they are spilled)
+    const int p = lz & 3, ox = (lz >> 4) * 4 + ((lz & 15) >> 2);   // this lane's row segment: strip pixel ox (and ox + 16: same & 7)
+    uint4 af[4];                                          // dy fragments of rows r - 2 .. r + 1 (the next one in flight): rows n (lane fr), k-slots = 32 pixels
+    uint4 bq[2][6];                                       // x fragments of two consecutive halo rows: [tap column][channel tile]
+    auto rdA = [&](int oy, uint4& f) {
+      f = tr_frag(gt + (oy * TW + ox) * 128 + (((2 * wv + (p >> 1)) ^ (ox & 7)) << 4) + (p & 1) * 8, 16 * 128);
+    };
+    auto rdB = [&](int r, uint4 (&f)[6]) {
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int cx = kx + ox;
-        const unsigned char* rb = tile + (oy * CPX + cx) * 128 + (p & 1) * 8;
+        const unsigned char* rb = tile + (r * CPX + cx) * 128 + (p & 1) * 8;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const int co = ((2 * ct + (p >> 1)) ^ (cx & 7)) << 4;
+        for (int c2 = 0; c2 < 2; ++c2) f[2 * kx + c2] = tr_frag(rb + (((2 * (2 * ce + c2) + (p >> 1)) ^ (cx & 7)) << 4), 16 * 128);
+      }
+    };
+    rdA(0, af[0]);
+    rdB(0, bq[0]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky) {
-            const uint4 xb = tr_frag(rb + ky * (CPX * 128) + co, 16 * 128);
-            mma16<bf16>(acc[ky * 3 + kx][ct], ga, xb);
-          }
+    for (int r = 0; r < G_TH + 2; ++r) {
+      if (r + 1 < G_TH + 2) rdB(r + 1, bq[(r + 1) & 1]);
+      if (r + 1 < G_TH) rdA(r + 1, af[(r + 1) & 3]);
+      int nm = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int oy = r - ky;
+        if (oy >= 0 && oy < G_TH) {
+          if (ky == 0) { mma16<bf16>(accb, af[oy & 3], ones); ++nm; }
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) { mma16<bf16>(acc[ky * 3 + kx][c2], af[oy & 3], bq[r & 1][2 * kx + c2]); ++nm; }
         }
       }
+      const int nr = 24 * (r + 1 < G_TH + 2) + 2 * (r + 1 < G_TH);
+#pragma unroll
+      for (int q = 0; q < 26; ++q)
+        if (q < nm && q < nr) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
     }
     cur = nxt;
   }
-  // acc[tap][ct][r] = dW[n = 16 wv + 4 fg + r][tap][c = 16 ct + fr]: every (wave, lane, r) owns its own entries of the partial
-  float* dst = part + ((long)blockIdx.x * 2 + par) * G_PART;
+  // acc[tap][c2][r] = dW[n = 16 wv + 4 fg + r][tap][c = 16 (2 ce + c2) + fr]: every (wave, lane, r) owns its own entries of the partial
+  float* dst = part + (long)blockIdx.x * G_PART;
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(16 * wv + 4 * fg + r) * 577 + tp * 64 + 16 * ct + fr] = acc[tp][ct][r];
-  if (fr == 0)
+      for (int r = 0; r < 4; ++r) dst[(16 * wv + 4 * fg + r) * 577 + tp * 64 + 16 * (2 * ce + c2) + fr] = acc[tp][c2][r];
+  if (fr == 0 && ce == 0)
 #pragma unroll
     for (int r = 0; r < 4; ++r) dst[(16 * wv + 4 * fg + r) * 577 + 576] = accb[r];
 }
@@ -700,7 +726,7 @@ int sodt_conv3x3_c64_fwd(const void* x, const void* w, const float* bias, const 
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
-long sodt_conv3x3_c64_wgrad_scratch_bytes(void) { return (long)(GRID / 2) * 2 * G_PART * 4; }
+long sodt_conv3x3_c64_wgrad_scratch_bytes(void) { return (long)(GRID / 2) * G_PART * 4; }
 
 int sodt_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, const sodt_conv3_geo* geo,
                            int dtype, hipStream_t st) {
@@ -712,7 +738,7 @@ int sodt_conv3x3_c64_wgrad(const void* dy, const void* x, float* dw, float* db, 
   const int grid = (int)(t.ntiles < GRID / 2 ? ((t.ntiles + 7) / 8) * 8 : GRID / 2);       // one 8-wave workgroup per CU
   hipLaunchKernelGGL(conv3_c64_wgrad_kernel, dim3(grid), dim3(512), 0, st, (const bf16*)dy, (const bf16*)x, scratch, t, dm, geo ? geo->out_i : 0,
                      geo ? geo->out_j : 0);
-  hipLaunchKernelGGL(conv3_c64_wgrad_reduce_kernel, dim3((G_PART + 63) / 64), dim3(256), 0, st, (const float*)scratch, 2 * grid, dw, db,
+  hipLaunchKernelGGL(conv3_c64_wgrad_reduce_kernel, dim3((G_PART + 63) / 64), dim3(256), 0, st, (const float*)scratch, grid, dw, db,
                      geo ? geo->w_row_stride : 1, geo ? geo->w_row_off : 0);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
