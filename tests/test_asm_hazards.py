@@ -154,6 +154,10 @@ SPILL_LIMITS = [
     # <SAVE, STAMP>: the training builds of the fused block may spill in the cold exact-softmax fallback only (checked above: never
     # while a read is in flight)
     ("wmsa_hg", "wmsa_hg_kernel", lambda n: 4 if "ILb1E" in n.split("wmsa_hg_kernel")[1][:6] else 0),
+    # the direct 3x3 kernels keep 18 weight fragments + a tile prefetch in registers (202-254 VGPRs): a spill lands in their row loops
+    ("conv3", "conv3_c64_kernel", lambda n: 0),
+    ("conv3", "conv3_c64_wgrad_kernel", lambda n: 0),
+    ("conv3", "conv3_n8_", lambda n: 0),
 ]
 
 
