@@ -316,7 +316,11 @@ int sodt_cross_attn_ln_bwd(const float* e, const float* gamma, const void* dout,
 /* BatchNorm2d (eps 1e-3, momentum 0.03) + SiLU of the head's Conv (common.py:38-50,
  * torch_utils.py:150-152), token-major.  stats f64 [SODT_STATS_REPL][2][C] from SODT_EPI_STATS.
  * finalize: mean/rstd (f32 [2][C]) + running-stat update (unbiased var); stats == NULL
- * takes mean/rstd from the running statistics (eval). */
+ * takes mean/rstd from the running statistics (eval).
+ * sodt_col_stats: the same statistics from a STORED convolution output z [M][ldz] (stats[r][0][c] += sum_m z, stats[r][1][c] += sum_m z^2,
+ * f64, one replica r per workgroup) - for the convolutions that run on the direct 3x3 kernels (csrc/conv3.hip), which have no
+ * statistics epilogue. */
+int sodt_col_stats(const void* z, int ldz, double* stats, long M, int C, int dtype, sodt_stream_t st);
 int sodt_bn_finalize(const double* stats, float* mean_rstd, float* running_mean, float* running_var,
                      long count, int C, float eps, float momentum, sodt_stream_t st);
 /* scale = gamma*rstd, shift = beta - mean*scale: the fused / eval-mode form (torch_utils.py:182-203) */

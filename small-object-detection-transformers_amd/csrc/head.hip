@@ -61,6 +61,52 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// per-channel  stats[r][0][c] += sum_m z,  stats[r][1][c] += sum_m z^2  (the BatchNorm batch statistics of a convolution whose kernel has no
+// statistics epilogue: csrc/conv3.hip); replica r = blockIdx.x % SODT_STATS_REPL as in the GEMM epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ z, int ldz, double* __restrict__ stats, long M, int C) {
+  constexpr int KPL = TT<T>::KPL;
+  __shared__ float sred[2][256 * KPL];
+  const int CH = C / KPL;
+  const int rpp = 256 / CH;                  // rows per pass
+  const int tid = threadIdx.x;
+  const int rl = tid / CH, ch = tid - rl * CH;
+  const bool act = rl < rpp;
+  const int c0 = ch * KPL;
+  float a0[KPL], a1[KPL];
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+  if (act) {
+    const long stride = (long)gridDim.x * rpp;
+    for (long m = (long)blockIdx.x * rpp + rl; m < M; m += 4 * stride) {
+      uint4 vq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long mm = m + u * stride;
+        vq[u] = mm < M ? *(const uint4*)(z + mm * ldz + c0) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[KPL];
+        unpack<T>(vq[u], v);
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) { a0[j] += v[j]; a1[j] = fmaf(v[j], v[j], a1[j]); }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) { sred[0][tid * KPL + j] = a0[j]; sred[1][tid * KPL + j] = a1[j]; }
+  __syncthreads();
+  double* st = stats + (size_t)(blockIdx.x % SODT_STATS_REPL) * 2 * C;
+  for (int c = tid; c < C; c += 256) {
+    const int cc = c / KPL, j = c - cc * KPL;
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < rpp; ++r) { s0 += sred[0][(r * CH + cc) * KPL + j]; s1 += sred[1][(r * CH + cc) * KPL + j]; }
+    atomicAdd(st + c, s0);
+    atomicAdd(st + C + c, s1);
+  }
+}
+
 // per-channel  red[0][c] += sum_m g,  red[1][c] += sum_m g * xhat,   g = dy * silu'(a)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z,
@@ -366,6 +412,17 @@ extern "C" int sodt_bn_silu_bwd_reduce(const void* dy, int lddy, const void* z, 
   long gr = (M + rpp - 1) / rpp; if (gr > 1024) gr = 1024;
   if (dtype == SODT_BF16) hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<bf16>, dim3((unsigned)gr), dim3(256), 0, (hipStream_t)st, (const bf16*)dy, lddy, (const bf16*)z, mean_rstd, gamma, beta, red, M, C);
   else if (dtype == SODT_F32) hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<float>, dim3((unsigned)gr), dim3(256), 0, (hipStream_t)st, (const float*)dy, lddy, (const float*)z, mean_rstd, gamma, beta, red, M, C);
+  else return SODT_EINVAL;
+  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
+}
+
+extern "C" int sodt_col_stats(const void* z, int ldz, double* stats, long M, int C, int dtype, sodt_stream_t st) {
+  const int kpl = dtype == SODT_BF16 ? 8 : 4;
+  if (!z || !stats || M <= 0 || C <= 0 || (C % kpl) || (ldz % kpl) || C / kpl > 256 || (((uintptr_t)z) & 15)) return SODT_EINVAL;
+  const int rpp = 256 / (C / kpl);
+  long gr = (M + 4L * rpp - 1) / (4L * rpp); if (gr > 1024) gr = 1024;
+  if (dtype == SODT_BF16) hipLaunchKernelGGL(col_stats_kernel<bf16>, dim3((unsigned)gr), dim3(256), 0, (hipStream_t)st, (const bf16*)z, ldz, stats, M, C);
+  else if (dtype == SODT_F32) hipLaunchKernelGGL(col_stats_kernel<float>, dim3((unsigned)gr), dim3(256), 0, (hipStream_t)st, (const float*)z, ldz, stats, M, C);
   else return SODT_EINVAL;
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }

@@ -179,6 +179,7 @@ class Engine:
         # 2x2-conv MLPs (bf16): fc1 folded into the convolution's weights (csrc/convmlp.hip) - no fc1 GEMM, and in the backward no
         # d(x) = du W1 and no dW1 GEMM; widths above this run the three-GEMM form (the composition kernels are plain f32 loops)
         self.convmlp_fold_maxc = 384
+        self.use_direct_conv3 = True   # the head's 3x3 Conv at 64 -> 64 channels on the direct kernels (csrc/conv3.hip) against the nine-segment GEMM
         # LayerNorm backward as the epilogue of the GEMM that produces its input gradient (SODT_EPI_LNBWD): built and pinned
         # (tests/test_kernels_gpu.py), but measured SLOWER than the two launches it replaces at the bench shapes (0.45 vs 0.34 ms
         # at K = 576: profiles/r04_lnfold_ab.md), so the step does not use it
@@ -911,7 +912,15 @@ class Engine:
             z = plan.buf(tag + ".z", (M, Cout))
             stats = plan.zbuf("f", tag + ".stats", (L.STATS_REPL, 2, Cout), torch.float64)   # zeroed with the pool (_forward_main)
             mr = plan.buf(tag + ".mr", (2, Cout), torch.float32)
-            ops.gemm_nt(segs, w[wname], z, M, Cout, K, spatial=spatial, stats=stats)
+            direct = self._direct3(plan, segs, K, Cout, k)
+            if direct:
+                # the 3x3 at 64 -> 64 channels of the stride-4 C3's Bottleneck: the direct kernel reads its input once (csrc/conv3.hip;
+                # the nine-segment GEMM ran at 0.11-0.15 of its HBM roofline), the batch statistics come from the stored output
+                H, W = spatial
+                ops.conv3_c64_fwd(segs[4].t, w[wname], z, M // (H * W), H, W)
+                ops.col_stats(z, stats, M, Cout)
+            else:
+                ops.gemm_nt(segs, w[wname], z, M, Cout, K, spatial=spatial, stats=stats)
             ops.bn_finalize(stats, mr, bufs[pname + "bn.running_mean"], bufs[pname + "bn.running_var"], M, Cout, 1e-3, 0.03)
             ops.bn_silu_fwd(z, mr, p[pname + "bn.weight"], p[pname + "bn.bias"], y, ldy, M, Cout)
         else:
@@ -920,8 +929,17 @@ class Engine:
             ops.bn_finalize(None, mr, bufs[pname + "bn.running_mean"], bufs[pname + "bn.running_var"], M, Cout, 1e-3, 0.03)
             ops.bn_affine(mr, p[pname + "bn.weight"], p[pname + "bn.bias"], sc[0], sc[1], Cout)
             ops.gemm_nt(segs, w[wname], y, M, Cout, K, spatial=spatial, affine=(sc[0], sc[1]), ldc=ldy)
-        plan.saved[tag] = dict(segs=segs, spatial=spatial, M=M, K=K, Cout=Cout, k=k, pname=pname)
+        plan.saved[tag] = dict(segs=segs, spatial=spatial, M=M, K=K, Cout=Cout, k=k, pname=pname,
+                               direct=bool(plan.training and not self.fused and self._direct3(plan, segs, K, Cout, k)))
         return y
+
+    def _direct3(self, plan, segs, K, Cout, k):
+        """a 3x3 Conv at 64 -> 64 channels on one dense bf16 tensor: sodt_conv3x3_c64_* (forward, input gradient, weight gradient)"""
+        if not (self.use_direct_conv3 and k == 3 and Cout == 64 and K == 576 and plan.dt == torch.bfloat16 and len(segs) == 9):
+            return False
+        s0 = segs[4]
+        return (s0.klen == 64 and s0.ld == 64 and s0.coff == 0 and s0.shr == 0 and s0.mul == 1 and s0.dy == 0 and s0.dx == 0
+                and all(s_.t is s0.t for s_ in segs))
 
     def _conv_bwd(self, plan, tag, dy, lddy, dy_off):
         """BN+SiLU backward and the conv weight gradient; returns dz (gradient at the conv output)."""
@@ -936,8 +954,13 @@ class Engine:
         ops.bn_silu_bwd_apply(dy, lddy, b[tag + ".z"], b[tag + ".mr"], p[pname + "bn.weight"], p[pname + "bn.bias"], red, dz,
                               g[pname + "bn.weight"], g[pname + "bn.bias"], M, Cout, dy_off=dy_off)
         cin = K // (k * k)
-        ops.gemm_tn(dz, sv["segs"], g[pname + "conv.weight"], M, Cout, K, spatial=sv["spatial"],
-                    kperm=(cin, k * k) if k > 1 else None)
+        if sv.get("direct"):
+            H, W = sv["spatial"]
+            scr = plan.buf("g.c64.scratch", (ops.conv3_c64_wgrad_scratch_floats(),), torch.float32)
+            ops.conv3_c64_wgrad(dz, sv["segs"][4].t, g[pname + "conv.weight"], None, scr, M // (H * W), H, W)
+        else:
+            ops.gemm_tn(dz, sv["segs"], g[pname + "conv.weight"], M, Cout, K, spatial=sv["spatial"],
+                        kperm=(cin, k * k) if k > 1 else None)
         return dz
 
     def _c3_fwd(self, plan, P, tag, pname, segs, spatial, M, c1, c2):
@@ -966,8 +989,11 @@ class Engine:
         ops.gemm_nt([SegSpec(dzb)], wT[pname + "cv2.conv.weight"], din, M, c1, c_)
         dza3 = self._conv_bwd(plan, tag + ".m2", dcat, 2 * c_, 0)
         da = plan.buf(tag + ".da", (M, c_))
-        segs = [SegSpec(dza3, c_, 0, -dy, -dx, 1, 0, H, W) for (dy, dx) in TAPS3]
-        ops.gemm_nt(segs, wT[pname + "m.0.cv2.conv.weight"], da, M, c_, 9 * c_, spatial=(H, W))
+        if plan.saved[tag + ".m2"].get("direct"):
+            ops.conv3_c64_fwd(dza3, wT[pname + "m.0.cv2.conv.weight"], da, M // (H * W), H, W, flip=True)
+        else:
+            segs = [SegSpec(dza3, c_, 0, -dy, -dx, 1, 0, H, W) for (dy, dx) in TAPS3]
+            ops.gemm_nt(segs, wT[pname + "m.0.cv2.conv.weight"], da, M, c_, 9 * c_, spatial=(H, W))
         dza2 = self._conv_bwd(plan, tag + ".m1", da, c_, 0)
         ops.gemm_nt([SegSpec(dza2)], wT[pname + "m.0.cv1.conv.weight"], da, M, c_, c_)
         dza1 = self._conv_bwd(plan, tag + ".cv1", da, c_, 0)

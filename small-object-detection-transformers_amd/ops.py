@@ -468,6 +468,11 @@ def bn_silu_fwd(z, mean_rstd, gamma, beta, y, ldy, M, Cc):
     _launch("sodt_bn_silu_fwd", _p(z), _p(mean_rstd), _p(gamma), _p(beta), _p(y), ldy, M, Cc, dt_code(z))
 
 
+def col_stats(z, stats, M, Cc):
+    """stats [STATS_REPL][2][C] f64 += column sums / sums of squares of z [M][ld] (BatchNorm batch statistics of a stored conv output)."""
+    _launch("sodt_col_stats", z.data_ptr(), z.shape[-1], stats.data_ptr(), C.c_long(M), Cc, dt_code(z))
+
+
 def bn_silu_bwd_reduce(dy, lddy, z, mean_rstd, gamma, beta, red, M, Cc, dy_off=0):
     _launch("sodt_bn_silu_bwd_reduce", dy.data_ptr() + dy_off * dy.element_size(), lddy, _p(z), _p(mean_rstd), _p(gamma),
             _p(beta), _p(red), M, Cc, dt_code(z))

@@ -16,7 +16,10 @@ SETTINGS = {
     "no conv-MLP fold": {"convmlp_fold_maxc": 0},
     "no fused linear MLP": {"use_fused_mlp": False},
     "neither": {"convmlp_fold_maxc": 0, "use_fused_mlp": False},
+    "no direct 3x3 in the head": {"use_direct_conv3": False},
 }
+if os.environ.get("AB_ONLY"):            # a comma-separated subset (each setting owns a 31 GB workspace)
+    SETTINGS = {k: v for k, v in SETTINGS.items() if k in os.environ["AB_ONLY"].split(",")}
 x = torch.rand(8, 3, 1024, 1024, device=dev)
 ir = torch.rand(8, 3, 1024, 1024, device=dev)
 models = {}

@@ -76,6 +76,18 @@ def cost(name, args):
         B, H, W = (val(args[o + i]) for i in range(3))
         M = B * H * W           # one pass over the 64-channel tensor and one over the 8-column one; 8 (padded) output channels
         return (f"M={M} 64->8 3x3", M * (64 + 8) * ES, 2.0 * M * 576 * 8)
+    if name == "sodt_conv3x3_c64_fwd":
+        B, H, W, flags = (val(args[i]) for i in (6, 7, 8, 9))
+        M = B * H * W
+        nop = 2 + (1 if flags & (2 | 4096) else 0)
+        return (f"M={M} 64->64 3x3 flags={flags}", M * 64 * ES * nop + 64 * 576 * ES, 2.0 * M * 64 * 576)
+    if name == "sodt_conv3x3_c64_wgrad":
+        B, H, W = (val(args[i]) for i in (5, 6, 7))
+        M = B * H * W
+        return (f"M={M} 64->64 3x3 dW", M * 128 * ES + 2.0 * 64 * 576 * 4, 2.0 * M * 64 * 576)
+    if name == "sodt_col_stats":
+        M, C = val(args[3]), val(args[4])
+        return (f"M={M} C={C}", M * C * ES, 0.0)
     if name == "sodt_layernorm_fwd":
         M, C = val(args[5]), val(args[6])
         return (f"M={M} C={C}", M * (2 * C * ES + 8), 0.0)
