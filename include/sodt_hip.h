@@ -166,16 +166,21 @@ int sodt_nchw_f32_from_rows(const void* rows, int ld, float* y, int B, int C, in
 int sodt_rows_from_nchw_f32(const float* y, void* rows, int ld, int B, int C, int H, int W, int dtype, sodt_stream_t st);
 
 /* ---- EDSR's closing convolution (edsr.py:81-84: conv(n_feats = 64, num_channels, 3) = nn.Conv2d(64, ch, 3, padding = 1), edsr.py:9-12),
- * forward and both gradients, on token-major rows (csrc/conv3.hip).  At most 8 output channels; bf16 only (SODT_EINVAL otherwise: the
+ * forward and both gradients, on token-major rows (csrc/conv3.hip).  cout <= 8 output channels; bf16 only (SODT_EINVAL otherwise: the
  * float32 path runs the convolution as nine K-segments of sodt_gemm_nt / sodt_gemm_tn).  Each launch moves its tensors once.
- *   fwd:   y [B*H*W][8] = x [B*H*W][64] (*) w + bias; w [8][9*64] = [n][tap*64 + c] (tap = 3 ky + kx; rows >= Cout zero), bias f32[8] or NULL.
- *   dgrad: dx [B*H*W][64] = dy [B*H*W][8] (*)^T wT;  wT [64][9*8] = [c][tap*8 + n] (columns >= Cout zero).
- *   wgrad: dw [cout][64][3][3] (the torch layout) += dy^T x(taps), db [cout] += column sums of dy (db may be NULL); scratch:
- *          sodt_conv3x3_c64n8_wgrad_scratch_bytes() bytes of f32 (per-workgroup partials, summed in a fixed order by a second launch). */
-int sodt_conv3x3_c64n8_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int dtype, sodt_stream_t st);
-int sodt_conv3x3_c64n8_dgrad(const void* dy, const void* wT, void* dx, int B, int H, int W, int dtype, sodt_stream_t st);
-int sodt_conv3x3_c64n8_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, int cout, int dtype,
+ *   fwd:   y [B*H*W][8] = x [B*H*W][64] (*) w + bias; w [8][9*64] = [n][tap*64 + c] (tap = 3 ky + kx; rows >= cout zero), bias f32[8] or NULL.
+ *          y_nchw != NULL: the result goes to (B, cout, H, W) float32 instead (the branch's output at the model boundary,
+ *          deeplabedsr.py:73), unrounded; y is then unused and may be NULL.
+ *   dgrad: dx [B*H*W][64] = dy (*)^T wT;  wT [64][9*8] = [c][tap*8 + n] (columns >= cout zero).  dy [B*H*W][8] bf16 (columns >= cout zero),
+ *          or dy_nchw != NULL: (B, cout <= 4, H, W) float32, rounded to bf16 as it is read.
+ *   wgrad: dw [cout][64][3][3] (the torch layout) += dy^T x(taps), db [cout] += column sums of dy (db may be NULL); dy / dy_nchw as above;
+ *          scratch: sodt_conv3x3_c64n8_wgrad_scratch_bytes() bytes of f32 (per-workgroup partials, summed in a fixed order by a second launch). */
+int sodt_conv3x3_c64n8_fwd(const void* x, const void* w, const float* bias, void* y, float* y_nchw, int B, int H, int W, int cout, int dtype,
+                           sodt_stream_t st);
+int sodt_conv3x3_c64n8_dgrad(const void* dy, const float* dy_nchw, const void* wT, void* dx, int B, int H, int W, int cout, int dtype,
                              sodt_stream_t st);
+int sodt_conv3x3_c64n8_wgrad(const void* dy, const float* dy_nchw, const void* x, float* dw, float* db, float* scratch, int B, int H, int W,
+                             int cout, int dtype, sodt_stream_t st);
 long sodt_conv3x3_c64n8_wgrad_scratch_bytes(void);
 
 /* ---- the 3x3 convolutions of EDSR at 64 input channels and 64 output channels per launch (edsr.py:34-53 ResBlock: conv -> ReLU -> conv,

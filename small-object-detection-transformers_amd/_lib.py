@@ -135,9 +135,9 @@ SIGNATURES = {
     "sodt_convmlp_decompose": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "sodt_mlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "sodt_col_stats": [_P, _I, _P, _L, _I, _I, _P],
-    "sodt_conv3x3_c64n8_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "sodt_conv3x3_c64n8_dgrad": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "sodt_conv3x3_c64n8_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sodt_conv3x3_c64n8_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sodt_conv3x3_c64n8_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sodt_conv3x3_c64n8_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sodt_conv3x3_c64_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     "sodt_conv3x3_c64_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P],
     "sodt_debug_wmsa_stamps": [_P, _I],

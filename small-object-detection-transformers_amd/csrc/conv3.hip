@@ -57,7 +57,7 @@ __device__ __forceinline__ uint4 lds_rd16(const unsigned char* p) { return *(con
 constexpr int F_TH = 16, F_PIX = (F_TH + 2) * CPX, F_CH = F_PIX * 8, F_R = (F_CH + 255) / 256;   // 612 pixels, 4896 chunks, 20 rounds
 
 __global__ __launch_bounds__(256, 2) void conv3_n8_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, const float* __restrict__ bias,
-                                                             bf16* __restrict__ y, const Tiles t) {
+                                                             bf16* __restrict__ y, const Tiles t, float* __restrict__ ynchw, const int cout) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[F_PIX * 128];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, fr = lane & 15, fg = lane >> 4;
   // weights: A fragment ks = (tap, channel half): row n = fr (rows >= 8: zero), k = 32 ks + 8 fg ..
@@ -123,7 +123,15 @@ __global__ __launch_bounds__(256, 2) void conv3_n8_fwd_kernel(const bf16* __rest
             mma16<bf16>(acc, wf[(ky * 3 + kx) * 2 + hk], xb);
           }
       const int gy = y0 + oy, gx = x0 + hx + fr;
-      if (fg < 2 && gy < t.H && gx < t.W)
+      if (ynchw) {
+        // the branch's output at the model boundary, (B, cout, H, W) float32 (deeplabedsr.py:73), straight from the accumulators:
+        // sixteen consecutive pixels of one channel plane per store
+        if (fg < 2 && gy < t.H && gx < t.W) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * fg + r < cout) ynchw[(((long)b * cout + 4 * fg + r) * t.H + gy) * t.W + gx] = acc[r];
+        }
+      } else if (fg < 2 && gy < t.H && gx < t.W)
         *(uint2*)(y + (((long)b * t.H + gy) * t.W + gx) * 8 + 4 * fg) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
     }
     cur = nxt;
@@ -133,8 +141,20 @@ __global__ __launch_bounds__(256, 2) void conv3_n8_fwd_kernel(const bf16* __rest
 // ------------------------------------------------------------------------------------------------------------------ input gradient
 constexpr int D_TH = 16, D_PIX = (D_TH + 2) * CPX, D_R = (D_PIX + 255) / 256;     // 612 one-chunk pixels, 3 rounds
 
+// dy of the closing convolution either as rows [M][8] bf16 or as the (B, cout <= 4, H, W) float32 gradient of the branch's output:
+// four plane loads per pixel, rounded to bf16 on the way into the LDS tile (what sodt_rows_from_nchw_f32 did in a launch of its own)
+__device__ __forceinline__ uint4 nchw4_load(const float* __restrict__ p, long plane, int cout, bool ok) {
+  float f[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < cout) f[c] = p[c * plane];
+  }
+  return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), 0u, 0u);
+}
+
 __global__ __launch_bounds__(256, 2) void conv3_n8_dgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ wT, bf16* __restrict__ dx,
-                                                               const Tiles t) {
+                                                               const Tiles t, const float* __restrict__ dynchw, const int cout) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[D_PIX * 16];
   __shared__ __attribute__((aligned(16))) unsigned char patch[4][16 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, fr = lane & 15, fg = lane >> 4;
@@ -168,7 +188,8 @@ __global__ __launch_bounds__(256, 2) void conv3_n8_dgrad_kernel(const bf16* __re
       const int py = pix / CPX, px = pix - py * CPX;
       const int gy = y0 - 1 + py, gx = x0 - 1 + px;
       const bool ok = pix < D_PIX && (unsigned)gy < (unsigned)t.H && (unsigned)gx < (unsigned)t.W;
-      pf[r] = ok ? *(const uint4*)(gb + (unsigned)((py * t.W + px) * 16)) : make_uint4(0u, 0u, 0u, 0u);
+      if (dynchw) pf[r] = nchw4_load(dynchw + ((long)b * cout * t.H + gy) * t.W + gx, (long)t.H * t.W, cout, ok);
+      else pf[r] = ok ? *(const uint4*)(gb + (unsigned)((py * t.W + px) * 16)) : make_uint4(0u, 0u, 0u, 0u);
     }
   };
   long cur = tile_of(t, 0);
@@ -234,7 +255,7 @@ __device__ __forceinline__ uint4 tr_frag(const unsigned char* a, int hi) {
 }
 
 __global__ __launch_bounds__(256, 2) void conv3_n8_wgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, float* __restrict__ part,
-                                                               const Tiles t) {
+                                                               const Tiles t, const float* __restrict__ dynchw, const int cout) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[W_PIX * 128];          // x halo tile (swizzled chunks); the reduction table at the end
   __shared__ __attribute__((aligned(16))) unsigned char gt[W_TH * TW * 32];         // dy tile, rows padded to 16 columns (8 .. 15 zero)
   static_assert(W_PIX * 128 >= W_PART * 4, "reduction table fits the tile");
@@ -263,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void conv3_n8_wgrad_kernel(const bf16* __re
       pf[r] = ok ? *(const uint4*)(xb + (unsigned)((py * t.W + px) * 128 + ch * 16)) : make_uint4(0u, 0u, 0u, 0u);
     }
     const int gy = y0 + (tid >> 5), gx = x0 + (tid & 31);
-    pg = (gy < t.H && gx < t.W) ? *(const uint4*)(gb + (unsigned)(((tid >> 5) * t.W + (tid & 31)) * 16)) : make_uint4(0u, 0u, 0u, 0u);
+    if (dynchw) pg = nchw4_load(dynchw + ((long)b * cout * t.H + gy) * t.W + gx, (long)t.H * t.W, cout, gy < t.H && gx < t.W);
+    else pg = (gy < t.H && gx < t.W) ? *(const uint4*)(gb + (unsigned)(((tid >> 5) * t.W + (tid & 31)) * 16)) : make_uint4(0u, 0u, 0u, 0u);
   };
   long cur = tile_of(t, 0);
   if (cur >= 0) issue(cur);
@@ -682,27 +704,29 @@ inline bool ok_common(const void* a, const void* b, const void* c, int B, int H,
 
 extern "C" {
 
-int sodt_conv3x3_c64n8_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int dtype, hipStream_t st) {
-  if (!ok_common(x, w, y, B, H, W, dtype) || (((uintptr_t)bias) & 15)) return SODT_EINVAL;
+int sodt_conv3x3_c64n8_fwd(const void* x, const void* w, const float* bias, void* y, float* y_nchw, int B, int H, int W, int cout, int dtype,
+                           hipStream_t st) {
+  if (!ok_common(x, w, y_nchw ? (const void*)y_nchw : y, B, H, W, dtype) || (((uintptr_t)bias) & 15) || cout < 1 || cout > 8) return SODT_EINVAL;
   const Tiles t = make_tiles(B, H, W, F_TH);
-  hipLaunchKernelGGL(conv3_n8_fwd_kernel, dim3(GRID), dim3(256), 0, st, (const bf16*)x, (const bf16*)w, bias, (bf16*)y, t);
+  hipLaunchKernelGGL(conv3_n8_fwd_kernel, dim3(GRID), dim3(256), 0, st, (const bf16*)x, (const bf16*)w, bias, (bf16*)y, t, y_nchw, cout);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
-int sodt_conv3x3_c64n8_dgrad(const void* dy, const void* wT, void* dx, int B, int H, int W, int dtype, hipStream_t st) {
-  if (!ok_common(dy, wT, dx, B, H, W, dtype)) return SODT_EINVAL;
+int sodt_conv3x3_c64n8_dgrad(const void* dy, const float* dy_nchw, const void* wT, void* dx, int B, int H, int W, int cout, int dtype, hipStream_t st) {
+  if (!ok_common(dy_nchw ? (const void*)dy_nchw : dy, wT, dx, B, H, W, dtype) || cout < 1 || cout > 8 || (dy_nchw && cout > 4)) return SODT_EINVAL;
   const Tiles t = make_tiles(B, H, W, D_TH);
-  hipLaunchKernelGGL(conv3_n8_dgrad_kernel, dim3(GRID), dim3(256), 0, st, (const bf16*)dy, (const bf16*)wT, (bf16*)dx, t);
+  hipLaunchKernelGGL(conv3_n8_dgrad_kernel, dim3(GRID), dim3(256), 0, st, (const bf16*)dy, (const bf16*)wT, (bf16*)dx, t, dy_nchw, cout);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }
 
 long sodt_conv3x3_c64n8_wgrad_scratch_bytes(void) { return (long)GRID * W_PART * 4; }
 
-int sodt_conv3x3_c64n8_wgrad(const void* dy, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, int cout, int dtype,
-                             hipStream_t st) {
-  if (!ok_common(dy, x, scratch, B, H, W, dtype) || !dw || cout < 1 || cout > 8) return SODT_EINVAL;
+int sodt_conv3x3_c64n8_wgrad(const void* dy, const float* dy_nchw, const void* x, float* dw, float* db, float* scratch, int B, int H, int W, int cout,
+                             int dtype, hipStream_t st) {
+  if (!ok_common(dy_nchw ? (const void*)dy_nchw : dy, x, scratch, B, H, W, dtype) || !dw || cout < 1 || cout > 8 || (dy_nchw && cout > 4))
+    return SODT_EINVAL;
   const Tiles t = make_tiles(B, H, W, W_TH);
-  hipLaunchKernelGGL(conv3_n8_wgrad_kernel, dim3(GRID), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, scratch, t);
+  hipLaunchKernelGGL(conv3_n8_wgrad_kernel, dim3(GRID), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, scratch, t, dy_nchw, cout);
   hipLaunchKernelGGL(conv3_n8_wgrad_reduce_kernel, dim3((cout * 577 + 255) / 256), dim3(256), 0, st, (const float*)scratch, GRID, dw, db, cout);
   return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
 }

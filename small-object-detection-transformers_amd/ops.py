@@ -361,24 +361,25 @@ def conv3_n8_ok(t: torch.Tensor, cin: int, np_: int, k: int) -> bool:
     return t.dtype == torch.bfloat16 and cin == 64 and np_ == 8 and k == 3
 
 
-def conv3_n8_fwd(x, w, bias, y, B, H, W):
-    """y [B*H*W][8] = conv3x3(x [B*H*W][64]; w [8][576] = [n][tap*64 + c]) + bias (f32[8] or None)."""
-    _launch("sodt_conv3x3_c64n8_fwd", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, H, W, dt_code(x))
+def conv3_n8_fwd(x, w, bias, y, B, H, W, y_nchw=None, cout=8):
+    """y [B*H*W][8] = conv3x3(x [B*H*W][64]; w [8][576] = [n][tap*64 + c]) + bias (f32[8] or None); y_nchw (B, cout, H, W) float32:
+    the result goes there instead (unrounded) and y may be None."""
+    _launch("sodt_conv3x3_c64n8_fwd", x.data_ptr(), w.data_ptr(), _p(bias), _p(y), _p(y_nchw), B, H, W, cout, dt_code(x))
 
 
-def conv3_n8_dgrad(dy, wT, dx, B, H, W):
-    """dx [B*H*W][64] = conv3x3^T(dy [B*H*W][8]; wT [64][72] = [c][tap*8 + n])."""
-    _launch("sodt_conv3x3_c64n8_dgrad", dy.data_ptr(), wT.data_ptr(), dx.data_ptr(), B, H, W, dt_code(dy))
+def conv3_n8_dgrad(dy, wT, dx, B, H, W, dy_nchw=None, cout=8):
+    """dx [B*H*W][64] = conv3x3^T(dy [B*H*W][8] or dy_nchw (B, cout <= 4, H, W) float32; wT [64][72] = [c][tap*8 + n])."""
+    _launch("sodt_conv3x3_c64n8_dgrad", _p(dy), _p(dy_nchw), wT.data_ptr(), dx.data_ptr(), B, H, W, cout, dt_code(dx))
 
 
 def conv3_n8_wgrad_scratch_floats() -> int:
     return int(_lib.sodt_conv3x3_c64n8_wgrad_scratch_bytes()) // 4
 
 
-def conv3_n8_wgrad(dy, x, dw, db, scratch, B, H, W, cout):
-    """dw [cout][64][3][3] f32 += , db [cout] f32 += (or None); scratch: conv3_n8_wgrad_scratch_floats() float32."""
+def conv3_n8_wgrad(dy, x, dw, db, scratch, B, H, W, cout, dy_nchw=None):
+    """dw [cout][64][3][3] f32 += , db [cout] f32 += (or None); dy rows or dy_nchw float32; scratch: conv3_n8_wgrad_scratch_floats() float32."""
     assert dw.dtype == torch.float32 and dw.is_contiguous() and scratch.dtype == torch.float32
-    _launch("sodt_conv3x3_c64n8_wgrad", dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _p(db), scratch.data_ptr(), B, H, W, cout, dt_code(dy))
+    _launch("sodt_conv3x3_c64n8_wgrad", _p(dy), _p(dy_nchw), x.data_ptr(), dw.data_ptr(), _p(db), scratch.data_ptr(), B, H, W, cout, dt_code(x))
 
 
 def conv3_geo(w_row=(1, 0), inp=(1, 0, 0), out=(1, 0, 0)):

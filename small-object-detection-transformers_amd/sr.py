@@ -194,7 +194,7 @@ class SRBranch:
             return segs, sp
         if self._direct3(c, parts[0], out, ldc) and not relu and resid is None:
             # EDSR's closing 64 -> ch convolution (edsr.py:81-84): its own kernel reads the 64-channel input once (csrc/conv3.hip)
-            ops.conv3_n8_fwd(parts[0].t, c.w, c.bias_pad if c.bias is not None else None, out, M // (H * W), H, W)
+            ops.conv3_n8_fwd(parts[0].t, c.w, c.bias_pad if c.bias is not None else None, out, M // (H * W), H, W, cout=c.cout)
             return segs, sp
         ops.gemm_nt(segs, c.w, out, M, c.np_ if padded else c.cout, c.taps * c.cin, spatial=sp, bias=c.bias_pad if padded else c.bias,
                     relu=relu, resid=resid, ldc=ldc, c_off=c_off)
@@ -233,7 +233,7 @@ class SRBranch:
                 ops.conv3_n8_wgrad(dy, segs[4].t, self.g[name + ".weight"], self.g[name + ".bias"] if c.bias is not None else None, scr,
                                    B, H, W, c.cout)
             if dx is not None:
-                ops.conv3_n8_dgrad(dy, c.wT, dx, B, H, W)
+                ops.conv3_n8_dgrad(dy, c.wT, dx, B, H, W, cout=c.cout)
             return
         if wgrad and c.dw_pad is None:
             ops.gemm_tn(dy, segs, self.g[name + ".weight"].view(c.cout, -1), M, c.cout, c.taps * c.cin, ldy=lddy, spatial=sp,
@@ -349,10 +349,15 @@ class SRBranch:
             cur, gh, gw = pj, 2 * gh, 2 * gw
             j += 1
         ct = c[e + "tail.1"]
-        o = self._buf("e.o", (B * gh * gw, ct.np_))
-        self.f_o = self._conv(e + "tail.1", [SegSpec(cur)], gh, gw, B * gh * gw, o)
         y = torch.empty(B, ct.cout, gh, gw, device=self.dev, dtype=torch.float32)
-        ops.nchw_f32_from_rows(o, y, B, ct.cout, gh, gw)
+        if ops.conv3_n8_ok(cur, ct.cin, ct.np_, ct.k) and ct.cout <= 4 and cur.shape[-1] == 64:
+            # the closing convolution writes the (B, ch, 8H, 8W) float32 output itself (no [M][8] rows, no conversion launch)
+            ops.conv3_n8_fwd(cur, ct.w, ct.bias_pad if ct.bias is not None else None, None, B, gh, gw, y_nchw=y, cout=ct.cout)
+            self.f_o = ("direct", cur)
+        else:
+            o = self._buf("e.o", (B * gh * gw, ct.np_))
+            self.f_o = self._conv(e + "tail.1", [SegSpec(cur)], gh, gw, B * gh * gw, o)
+            ops.nchw_f32_from_rows(o, y, B, ct.cout, gh, gw)
         return y
 
     def edsr_backward(self, dy: torch.Tensor) -> torch.Tensor:
@@ -364,10 +369,18 @@ class SRBranch:
         gh, gw = H << nt, W << nt
         ct = c[e + "tail.1"]
         assert dy.dtype == torch.float32 and dy.is_contiguous() and tuple(dy.shape) == (B, ct.cout, gh, gw)
-        do = self._buf("g.o", (B * gh * gw, ct.np_))
-        ops.rows_from_nchw_f32(dy, do, B, ct.cout, gh, gw)
         dcur = self._buf(f"g.p{nt}", (B * gh * gw, 64))
-        self._conv_bwd(e + "tail.1", do, ct.np_, self.f_o, gh, gw, B * gh * gw, dcur)
+        if self.f_o[0] == "direct":
+            # ... and its gradients read the float32 (B, ch, 8H, 8W) gradient in place
+            name = e + "tail.1"
+            scr = self._buf("c3.scratch", (ops.conv3_n8_wgrad_scratch_floats(),), torch.float32)
+            ops.conv3_n8_wgrad(None, self.f_o[1], self.g[name + ".weight"], self.g[name + ".bias"] if ct.bias is not None else None, scr,
+                               B, gh, gw, ct.cout, dy_nchw=dy)
+            ops.conv3_n8_dgrad(None, ct.wT, dcur, B, gh, gw, dy_nchw=dy, cout=ct.cout)
+        else:
+            do = self._buf("g.o", (B * gh * gw, ct.np_))
+            ops.rows_from_nchw_f32(dy, do, B, ct.cout, gh, gw)
+            self._conv_bwd(e + "tail.1", do, ct.np_, self.f_o, gh, gw, B * gh * gw, dcur)
         for j in reversed(range(nt)):
             fj, hj, wj = self.f_t[j]
             dsrc = self._buf(f"g.p{j}", (B * hj * wj, 64))

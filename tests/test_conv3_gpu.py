@@ -86,6 +86,18 @@ def test_forward_and_gradients_vs_float64_conv2d(ops, B, H, W, cout):
     dw2 = torch.zeros_like(dw)
     ops.conv3_n8_wgrad(dyd, xd, dw2, None, scr, B, H, W, cout)
     assert torch.equal(dw2, dw - 0.5) or (dw2 - (dw - 0.5)).abs().max().item() <= 1e-5 * dw.abs().max().item()
+    if cout <= 4:
+        # the float32 (B, cout, H, W) boundary forms (deeplabedsr.py:73): output unrounded, gradient rounded to bf16 as it is read
+        yn = torch.full((B, cout, H, W), 7.0, device=dev)
+        ops.conv3_n8_fwd(xd, wg, bp, None, B, H, W, y_nchw=yn, cout=cout)
+        assert (yn.cpu().double() - ref.detach()).abs().max().item() <= 2e-5 * scale + 1e-5
+        dyn = dy.float().permute(0, 3, 1, 2).contiguous().to(dev)
+        dx3 = torch.empty_like(dx)
+        ops.conv3_n8_dgrad(None, wT, dx3, B, H, W, dy_nchw=dyn, cout=cout)
+        assert torch.equal(dx3, dx)
+        dw3, db3 = torch.zeros_like(dw), torch.zeros_like(db)
+        ops.conv3_n8_wgrad(None, xd, dw3, db3, scr, B, H, W, cout, dy_nchw=dyn)
+        assert torch.equal(dw3, dw2) and (db3 - (db + 0.25)).abs().max().item() <= 1e-5 * db.abs().max().item() + 1e-6
 
 
 def test_many_tiles_per_workgroup_bit_identical_to_itself_and_close_to_the_gemm_path(ops):
