@@ -47,9 +47,12 @@ def main():
         ms = (time.perf_counter() - t0) / a.steps * 1e3
         print(f"sr={sr}: B={a.batch} @ {a.size}^2 {a.dtype}: {ms:.1f} ms / step, {a.batch / ms * 1e3:.1f} img/s, "
               f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
-        del m
-        torch.cuda.empty_cache()
+        del m, step
+        import gc
+        gc.collect()                      # (the engine and its recorded plans refer to each other: without a collection the first model's
+        torch.cuda.empty_cache()          #  46 GiB workspace is still allocated while the second one runs and lands in its "peak")
         torch.cuda.reset_peak_memory_stats()
+        print(f"  (still allocated after this model: {torch.cuda.memory_allocated() / 2**30:.1f} GiB)", flush=True)
 
 
 if __name__ == "__main__":
