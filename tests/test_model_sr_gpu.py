@@ -162,11 +162,15 @@ def test_sr_step_at_2048_bf16_config5_size(dev):
     """BASELINE config 5's per-image size in the -m gpu suite: SRyolo_MF.yaml graph with the super-resolution branch
     at 2048^2 bf16, output_sr (B, 4, 4096, 4096).  B = 2 IDENTICAL images (the per-GPU share of B = 4 on two GPUs): finite outputs, image
     1 reproduces image 0 bit for bit (no cross-image coupling in the branch; the head's BatchNorm sees one image's statistics), finite
-    non-zero gradients in the branch and in the encoder, and a peak-memory bound (76 GiB per image pair measured in round 4)."""
+    non-zero gradients in the branch and in the encoder, and a bound on the memory this model adds at its peak (40 GiB per image pair in
+    round 5: half of the 79.9 GiB of B = 4; whatever earlier tests of the process still hold is subtracted)."""
+    import gc
     from oracle import ref_torch as R
     S = 2048
+    gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated() / 2 ** 30
     model, _ = build(dev, S)
     model.compute_dtype = torch.bfloat16
     model.train()
@@ -185,8 +189,8 @@ def test_sr_step_at_2048_bf16_config5_size(dev):
     assert gsum > 0
     enc = dict(model.named_parameters())["image_encoder.stage1.0.attn.qkv.weight"].grad
     assert bool(torch.isfinite(enc).all()) and float(enc.abs().max()) > 0
-    peak = torch.cuda.max_memory_allocated() / 2 ** 30
-    assert peak < 100.0, f"peak memory {peak:.1f} GiB at B=2 @2048^2 with the SR branch"
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30 - base
+    assert peak < 50.0, f"peak memory {peak:.1f} GiB (above the {base:.1f} GiB held before) at B=2 @2048^2 with the SR branch"
     del model, pred, out_sr
     torch.cuda.empty_cache()
 
