@@ -1351,9 +1351,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
             dbc[ms - ns + 3][r] += ds;
           }
         }
-        // this strip as (half of) the A operand of the query contractions: bf16 strips fill k-slots 0-3 (even strip) or
-        // 4-7 (odd strip) with zeros in the other half - twice the MFMAs of a packed pair (still < 2 % of the kernel),
-        // no operand registers held across strips.  dS strip -> [key][16 q] patch for dQ.
+        // this strip as the A operand of the query contractions: a bf16 strip is one 16-deep half of the 32-deep operand (k-slots
+        // 0-3 even strip, 4-7 odd strip) - the K = 16 MFMA on that half and the matching half of the B fragment (round 5; before:
+        // the 32-deep MFMA with zeros in the other half, 160 v_mov 0 per window and head).  Twice the MFMAs of a packed pair
+        // (still < 2 % of the kernel), no operand registers held across strips.  dS strip -> [key][16 q] patch for dQ.
 #pragma unroll
         for (int ns = 0; ns < 4; ++ns) {
           uint4 ap, ads;
@@ -1370,8 +1371,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
           }
 #pragma unroll
           for (int d = 0; d < HD / 16; ++d) {
-            mma16<T>(dv[ns][d], ap, fdo[d]);
-            mma16<T>(dk[ns][d], ads, fqq[d]);
+            if constexpr (std::is_same<T, bf16>::value) {
+              // the strip fills one 16-deep half of the operand: the K = 16 MFMA on that half (no zero registers, no v_mov 0)
+              typedef __attribute__((ext_vector_type(4))) short s16x4_;
+              union { uint2 u; s16x4_ v; } a1, a2, b1, b2;
+              a1.u = hh == 0 ? make_uint2(ap.x, ap.y) : make_uint2(ap.z, ap.w);
+              a2.u = hh == 0 ? make_uint2(ads.x, ads.y) : make_uint2(ads.z, ads.w);
+              b1.u = hh == 0 ? make_uint2(fdo[d].x, fdo[d].y) : make_uint2(fdo[d].z, fdo[d].w);
+              b2.u = hh == 0 ? make_uint2(fqq[d].x, fqq[d].y) : make_uint2(fqq[d].z, fqq[d].w);
+              dv[ns][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1.v, b1.v, dv[ns][d], 0, 0, 0);
+              dk[ns][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2.v, b2.v, dk[ns][d], 0, 0, 0);
+            } else {
+              mma16<T>(dv[ns][d], ap, fdo[d]);
+              mma16<T>(dk[ns][d], ads, fqq[d]);
+            }
           }
         }
         // dQ strip ms = dS K: A = dS[q = fr][keys] read transposed from the patch (same wave: LDS ops are in order),
