@@ -1379,8 +1379,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
               a2.u = hh == 0 ? make_uint2(ads.x, ads.y) : make_uint2(ads.z, ads.w);
               b1.u = hh == 0 ? make_uint2(fdo[d].x, fdo[d].y) : make_uint2(fdo[d].z, fdo[d].w);
               b2.u = hh == 0 ? make_uint2(fqq[d].x, fqq[d].y) : make_uint2(fqq[d].z, fqq[d].w);
-              dv[ns][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1.v, b1.v, dv[ns][d], 0, 0, 0);
-              dk[ns][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2.v, b2.v, dk[ns][d], 0, 0, 0);
+              // (operands swapped: the accumulators hold dV^T / dK^T - four consecutive CHANNELS of one key per lane - so that the
+              //  staging below is one 8-byte LDS write per tile instead of four 2-byte ones)
+              dv[ns][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(b1.v, a1.v, dv[ns][d], 0, 0, 0);
+              dk[ns][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(b2.v, a2.v, dk[ns][d], 0, 0, 0);
             } else {
               mma16<T>(dv[ns][d], ap, fdo[d]);
               mma16<T>(dk[ns][d], ads, fqq[d]);
@@ -1396,14 +1398,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
 #pragma unroll
           for (int d = 0; d < HD / 16; ++d) {
             const uint4 fkk = fragT<T>(myK, L::QROW, kb * MK, d * 16, lane);
-            if (kb == 0) dq[d] = mma16z<T>(fst, fkk); else mma16<T>(dq[d], fst, fkk);
+            if constexpr (std::is_same<T, bf16>::value) {      // dQ^T = K^T dS^T: four consecutive channels of one query per lane
+              if (kb == 0) dq[d] = mma16z<T>(fkk, fst); else mma16<T>(dq[d], fkk, fst);
+            } else {
+              if (kb == 0) dq[d] = mma16z<T>(fst, fkk); else mma16<T>(dq[d], fst, fkk);
+            }
           }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
+        if constexpr (std::is_same<T, bf16>::value) {
 #pragma unroll
           for (int d = 0; d < HD / 16; ++d)
-            st_elem<T>(myDQ + (ms * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dq[d][r] * scale);
+            *(uint2*)(myDQ + (ms * 16 + fr) * L::QROW + (d * 16 + 4 * fg) * E) =
+                make_uint2(pack2bf(dq[d][0] * scale, dq[d][1] * scale), pack2bf(dq[d][2] * scale, dq[d][3] * scale));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d)
+              st_elem<T>(myDQ + (ms * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E, dq[d][r] * scale);
+        }
       }
     }
     };
@@ -1415,16 +1428,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
       B2_ISSUE(nxt)
     }
     // ---- stage dQ / dK / dV through this head's own Q / K / V tiles, then coalesced stores
+    if constexpr (std::is_same<T, bf16>::value) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) {
-          const int off = (i * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E;
-          st_elem<T>(myK + off, dk[i][d][r] * sc_dk);
-          st_elem<T>(myV + off, dv[i][d][r]);
+          const int off = (i * 16 + fr) * L::QROW + (d * 16 + 4 * fg) * E;        // (transposed accumulators: key fr, channels 4 fg ..)
+          *(uint2*)(myK + off) = make_uint2(pack2bf(dk[i][d][0] * sc_dk, dk[i][d][1] * sc_dk), pack2bf(dk[i][d][2] * sc_dk, dk[i][d][3] * sc_dk));
+          *(uint2*)(myV + off) = make_uint2(pack2bf(dv[i][d][0], dv[i][d][1]), pack2bf(dv[i][d][2], dv[i][d][3]));
         }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int d = 0; d < HD / 16; ++d) {
+            const int off = (i * 16 + fg * 4 + r) * L::QROW + (d * 16 + fr) * E;
+            st_elem<T>(myK + off, dk[i][d][r] * sc_dk);
+            st_elem<T>(myV + off, dv[i][d][r]);
+          }
+    }
     __syncthreads();
     for (int idx = tid; idx < 64 * CPR; idx += NT) {
       const int r = idx / CPR, cc = idx - r * CPR;
