@@ -1304,6 +1304,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
     int krid[4];
 #pragma unroll
     for (int ns = 0; ns < 4; ++ns) krid[ns] = MSK ? (int)sGeoQ[ns * 16 + fr][2] : 0;
+    // the K fragments of S = Q K^T do not depend on the strip: read once per window (16 registers; the four V fragments would be the
+    // next 16, which the kernel does not have).  Same box, interleaved: 0.512-0.520 / 0.482-0.483 -> 0.488-0.497 / 0.459-0.461 ms.
+    uint4 fkh[4];
+    if constexpr (L::KBQ == 1) {
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) fkh[ns] = frag<T>(myK, L::QROW, ns * 16, 0, HD, lane);
+    }
 #pragma unroll
     for (int kbq = 0; kbq < 4 / SPK; ++kbq) {
       // B operands of the query contractions for this k-block (rows = the strip pair, transposed read)
@@ -1323,7 +1330,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd_fast2_kerne
           const uint4 fo = frag<T>(myDO, L::QROW, ms * 16, kb, HD, lane);
 #pragma unroll
           for (int ns = 0; ns < 4; ++ns) {
-            const uint4 fk = frag<T>(myK, L::QROW, ns * 16, kb, HD, lane);
+            const uint4 fk = (L::KBQ == 1) ? fkh[ns] : frag<T>(myK, L::QROW, ns * 16, kb, HD, lane);
             const uint4 fv = frag<T>(myV, L::QROW, ns * 16, kb, HD, lane);
             if (kb == 0) { s[ns] = mma16z<T>(fq, fk); dp[ns] = mma16z<T>(fo, fv); }
             else { mma16<T>(s[ns], fq, fk); mma16<T>(dp[ns], fo, fv); }
