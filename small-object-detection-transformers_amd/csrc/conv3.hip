@@ -1,3 +1,9 @@
+// Direct 3x3 convolutions (stride 1, padding 1) on token-major [B][H][W][64] bf16 rows for the 64-input-channel layers of EDSR
+// (edsr.py) - and the one such layer of the detection head (common.py:98-115, the stride-4 C3's Bottleneck).  Two families:
+//   * sodt_conv3x3_c64n8_*  - the closing convolution, 64 -> at most 8 channels (this comment);
+//   * sodt_conv3x3_c64_*    - 64 -> 64 channels per launch: the body's ResBlocks and, through sodt_conv3_geo, the upsampler stages
+//                             conv(64 -> 256) + PixelShuffle(2) as four plane launches (second half of the file).
+//
 // The closing convolution of EDSR (edsr.py:81-84 `conv(n_feats, num_channels, 3)` = nn.Conv2d(64, ch, 3, padding=1), edsr.py:9-12):
 // 64 -> at most 8 channels on the x8 grid - 67 M pixels at BASELINE config 5.  As a nine-segment GEMM it re-read its input nine
 // times through the CU memory path for 9 KFLOP per pixel (12.6 / 14.4 / 17.7 ms forward / input gradient / weight gradient); here
@@ -12,7 +18,8 @@
 //   * wgrad:    dW[n][tap][c] = sum over pixels dy[p][n] x[p + tap][c]: pixels are the contraction index, both operands come from
 //               LDS through the transposing read (ds_read_b64_tr_b16), 36 + 1 accumulator tiles per wave (the "+ 1" against a
 //               vector of ones is the bias gradient); one partial per workgroup, summed by a second launch (deterministic).
-// bf16 only (the float32 parity path keeps the K-segment GEMM).
+// The forward can store the (B, cout, H, W) float32 output of the branch directly, the gradients can read the float32 gradient planes
+// (deeplabedsr.py:73).  bf16 only (the float32 parity path keeps the K-segment GEMM).
 #include "common.h"
 #include "../../include/sodt_hip.h"
 
