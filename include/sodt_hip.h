@@ -279,7 +279,11 @@ int sodt_mlp_fwd(const void* xn, const void* w1, const float* b1, const void* w2
  * sodt_convmlp_border_sums: bs f32 [3][C] (zeroed by the caller) += sums of dc [B*H*W][C] over the last-column tokens, the last-row
  *   tokens and the corner tokens.
  * sodt_convmlp_decompose: parameter gradients by the chain rule from dweff f32 [C][4C] (= dc^T x(taps), sodt_gemm_tn without kperm),
- *   colsum f32 [C] (its dbias) and bs: g_conv_w [C][C][2][2], g_conv_b, g_fc1_w, g_fc1_b are ADDED to. */
+ *   colsum f32 [C] (its dbias) and bs: g_conv_w [C][C][2][2], g_conv_b, g_fc1_w, g_fc1_b are ADDED to.  C <= 384.
+ * Reproducibility: sodt_convmlp_border_sums and the fc1.weight part of sodt_convmlp_decompose sum their per-workgroup partials with
+ *   f32 atomicAdd (four k-quarters per tile / one partial per 8-token chunk), so g_fc1_w, g_fc1_b and g_conv_w of a folded MLP agree
+ *   run to run only to f32 summation order (~1e-7 relative) - unlike the weight gradients of sodt_gemm_tn and the direct 3x3 kernels,
+ *   which reduce their partial tiles in a fixed order and are bitwise reproducible. */
 int sodt_convmlp_compose(const float* fc1_w, const float* fc1_b, const float* conv_w, const float* conv_b, void* weff, void* weffT,
                          float* beff, float* vtap, int C, int dtype, sodt_stream_t st);
 int sodt_convmlp_border_fix(void* cp, void* ca, const float* vtap, int B, int H, int W, int C, int dtype, sodt_stream_t st);

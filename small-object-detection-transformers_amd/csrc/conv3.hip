@@ -374,10 +374,11 @@ __global__ __launch_bounds__(256) void conv3_n8_wgrad_reduce_kernel(const float*
 // 16 w + 15 (its 18 weight fragments resident in registers) of the 16-pixel strip h of all eight tile rows, so no weight ever goes
 // through LDS and the input crosses the CU once.  flip: the input gradient is the same correlation with the taps mirrored (tap' = 8 - tap) and the transposed weights.
 // Epilogue in the GEMM's order: + bias, ReLU, ReLU mask (aux > 0), + residual.
-// Every global access of the hot path is UNCONDITIONAL (out-of-image halo chunks read a zero buffer; tiles that stick out of the image
-// take a second, predicated instantiation): hipcc then counts vmcnt exactly, so the epilogue operands that are fetched four rows ahead
-// and the next tile's chunks stay in flight across the rows - with a predicated load anywhere in the loop it falls back to vmcnt(0)
-// before every row and the wave eats a memory latency sixteen times per tile.
+// The halo chunks of the next tile are PREDICATED loads (`ok ? load : 0` in issue(): out-of-image chunks are zeros), issued once per
+// tile ahead of the row walk.  What is unconditional is the EPILOGUE-operand fetch of the FULL instantiation (tiles inside the image;
+// tiles that stick out take the second, predicated instantiation): inside the row loop hipcc then counts vmcnt exactly, so the operands
+// fetched four rows ahead stay in flight across the rows - with a predicated load inside that loop it falls back to vmcnt(0) before
+// every row and the wave eats a memory latency sixteen times per tile.
 // Geometry maps (sodt_conv3_geo, include/sodt_hip.h): the input pixel (y, x) of the H x W grid the kernel walks may live at
 // (im y + ii, im x + ij) of an (im H) x (im W) tensor, the output pixel likewise (om, oi, oj), and output channel n may take weight /
 // bias row wrs n + wro.  With (4, 2 i + j) and om = 2 a 64 -> 256 convolution + nn.PixelShuffle(2) (edsr.py:19-24) is four launches that
@@ -387,8 +388,6 @@ struct C64Args {
   int flags, flip;
   int wrs, wro, im, ii, ij, om, oi, oj;
 };
-
-__device__ __attribute__((aligned(16))) unsigned int c3_zero16[4] = {0u, 0u, 0u, 0u};
 
 constexpr int C_TH = 8, C_PIX = (C_TH + 2) * CPX, C_CH = C_PIX * 8, C_R = (C_CH + 511) / 512;   // 340 pixels, 2720 chunks, 6 rounds of 512 threads
 

@@ -28,6 +28,7 @@ namespace {
 //      through LDS, thread (ty, tx) = (tid / 16, tid % 16) owns the 4 x 4 outputs (ty + 16 i, tx + 16 j).  la(r, k) / lb(k, c): global loads
 //      of one element of the A / B tile (r, c in 0..63 relative to the tile, k absolute); *_k_fast says which index runs along the lanes.
 constexpr int CT = 64, CK = 16;
+constexpr int CONVMLP_MAXC = 384;                 // widest folded MLP (stage 2); the decompose kernel's bias tail holds 4 C floats in LDS
 template <typename LA, typename LB>
 __device__ __forceinline__ void tile64(float (&acc)[4][4], int K, float (*As)[CT + 1], float (*Bs)[CT + 1], LA la, LB lb, bool a_k_fast, bool b_k_fast) {
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256) void convmlp_decompose_kernel(const float* __r
                                                                 float* __restrict__ gWc, float* __restrict__ gbc, float* __restrict__ gW1,
                                                                 float* __restrict__ gb1, int C) {
   __shared__ float As[CK][CT + 1], Bs[CK][CT + 1];
+  __shared__ float dvs[4 * CONVMLP_MAXC];          // dv[t][co] of the bias tail (its own array: 4 C floats do not fit As at C = 384)
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   const int nt = C / CT, n = nt * nt;
   // dv[t][co] = colsum[co] - (sum of dc over the tokens whose tap t is outside): t = 1 right column, t = 2 bottom row, t = 3 either
@@ -220,7 +222,6 @@ __global__ __launch_bounds__(256) void convmlp_decompose_kernel(const float* __r
   // ---- the last C / 32 workgroups: gb1[m] += sum_t sum_co Wc[co][m][t] dv[t][co] and gbc += colsum, 32 values of m each, eight lanes
   //      per m over the co's (one workgroup walking all of it serially was the longest pole of the launch: 40 of its 51 us at C = 192)
   bid -= 4 * n;
-  float* dvs = &As[0][0];                          // dv[t][co] in LDS: 4 C floats <= 16 x 65
   for (int i = tid; i < 4 * C; i += 256) dvs[i] = dv(i / C, i % C);
   __syncthreads();
   const int m = bid * 32 + (tid >> 3), part = tid & 7;
@@ -271,7 +272,7 @@ extern "C" int sodt_convmlp_decompose(const float* dweff, const float* colsum, c
                                       const float* conv_w, float* g_conv_w, float* g_conv_b, float* g_fc1_w, float* g_fc1_b, int C,
                                       sodt_stream_t st) {
   if (!dweff || !colsum || !bs || !fc1_w || !fc1_b || !conv_w || !g_conv_w || !g_conv_b || !g_fc1_w || !g_fc1_b || C <= 0 || (C % 64) ||
-      ((((uintptr_t)conv_w) | ((uintptr_t)g_conv_w)) & 15))
+      C > CONVMLP_MAXC || ((((uintptr_t)conv_w) | ((uintptr_t)g_conv_w)) & 15))
     return SODT_EINVAL;
   const int n = (C / 64) * (C / 64);
   hipLaunchKernelGGL(convmlp_decompose_kernel, dim3(8 * n + C / 32), dim3(256), 0, (hipStream_t)st, dweff, colsum, bs, fc1_w, fc1_b, conv_w,

@@ -174,6 +174,14 @@ class SRBranch:
             t = self.bufs[name] = torch.zeros(shape, device=self.dev, dtype=self.dt if dtype is None else dtype)
         return t
 
+    @staticmethod
+    def _bias8(c):
+        """bias operand of the direct 64 -> <= 8 kernel (it reads 8 floats): the zero-padded copy when cout < 8; at cout == 8 there is
+        no padded copy (np_ == cout) and the parameter itself already holds the 8 floats (advisor r5)."""
+        if c.bias is None:
+            return None
+        return c.bias_pad if c.bias_pad is not None else c.bias
+
     def _conv(self, name, parts: Sequence[SegSpec], H, W, M, out, *, relu=False, resid=None, ldc=None, c_off=0):
         """out[:, c_off : c_off + Cout] = act(conv(name)(input) + bias) [+ resid]; `parts`: the input as channel segments.
         Returns the K-segments (the weight gradient re-reads them)."""
@@ -194,7 +202,7 @@ class SRBranch:
             return segs, sp
         if self._direct3(c, parts[0], out, ldc) and not relu and resid is None:
             # EDSR's closing 64 -> ch convolution (edsr.py:81-84): its own kernel reads the 64-channel input once (csrc/conv3.hip)
-            ops.conv3_n8_fwd(parts[0].t, c.w, c.bias_pad if c.bias is not None else None, out, M // (H * W), H, W, cout=c.cout)
+            ops.conv3_n8_fwd(parts[0].t, c.w, self._bias8(c), out, M // (H * W), H, W, cout=c.cout)
             return segs, sp
         ops.gemm_nt(segs, c.w, out, M, c.np_ if padded else c.cout, c.taps * c.cin, spatial=sp, bias=c.bias_pad if padded else c.bias,
                     relu=relu, resid=resid, ldc=ldc, c_off=c_off)
@@ -352,7 +360,7 @@ class SRBranch:
         y = torch.empty(B, ct.cout, gh, gw, device=self.dev, dtype=torch.float32)
         if ops.conv3_n8_ok(cur, ct.cin, ct.np_, ct.k) and ct.cout <= 4 and cur.shape[-1] == 64:
             # the closing convolution writes the (B, ch, 8H, 8W) float32 output itself (no [M][8] rows, no conversion launch)
-            ops.conv3_n8_fwd(cur, ct.w, ct.bias_pad if ct.bias is not None else None, None, B, gh, gw, y_nchw=y, cout=ct.cout)
+            ops.conv3_n8_fwd(cur, ct.w, self._bias8(ct), None, B, gh, gw, y_nchw=y, cout=ct.cout)
             self.f_o = ("direct", cur)
         else:
             o = self._buf("e.o", (B * gh * gw, ct.np_))
