@@ -73,11 +73,8 @@ typedef struct {
 #define SODT_EPI_RELU 2048       /* v = max(v, 0) after the bias: the ReLUs of the super-resolution branch (sr_decoder_noBN_noD.py:30-38,
                                   * edsr.py:44) */
 #define SODT_EPI_DRELU 4096      /* v = aux[m][n] > 0 ? v : 0 - the gradient through a ReLU whose OUTPUT is aux (applied before RESID) */
-#define SODT_EPI_LNBWD 1024      /* the GEMM's result dy = A W^T is the gradient of a LayerNorm's OUTPUT and never stored: C = [R +]
-                                  * LN'(dy) with x = aux [M][ldaux], (mean, rstd) = scale (f32 [M][2]), gamma = shift (f32 [N]);
-                                  * ln_dgamma / ln_dbeta (f32 [N]) += the parameter gradients.  bf16 pipelined kernel only, N == 192 (a token row in one
-                                  * workgroup), one plain K-segment; optional SODT_EPI_RESID (the residual path's gradient).
-                                  * backbone_vit.py:1089,1128 (norm1 / norm2 of SwinTransformerBlock) */
+/* (1024 was SODT_EPI_LNBWD, rounds 4-5: the LayerNorm backward as a GEMM epilogue - built, pinned, slower than the two launches it
+ * replaced (profiles/r04_lnfold_ab.md) and removed in round 6; the bit is not reused) */
 
 typedef struct {
   sodt_aspec a;                 /* A [M][K] as K-segments */
@@ -92,7 +89,6 @@ typedef struct {
   int M, N, K, flags;
   int oscatter, omul, ody, odx, OH, OW;   /* optional output-row scatter (PatchMerging backward) */
   int det_na, det_no, det_hw;
-  float* ln_dgamma; float* ln_dbeta;      /* SODT_EPI_LNBWD: f32 [N] each, += (atomics) */
 } sodt_gemm_args;
 
 /* C = epilogue(A @ W^T): every nn.Linear / 1x1 / 2x2 / 3x3 Conv2d forward and every

@@ -26,7 +26,7 @@ MAX_SEG = 9
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_RESID, EPI_GELU_DUAL, EPI_DGELU = 1, 2, 4, 8
 EPI_STATS, EPI_AFFINE_SILU, EPI_DETECT, EPI_OUT_F32 = 16, 32, 64, 128
-EPI_GELU, EPI_DGELU_RC, EPI_LNBWD, EPI_RELU, EPI_DRELU = 256, 512, 1024, 2048, 4096
+EPI_GELU, EPI_DGELU_RC, EPI_RELU, EPI_DRELU = 256, 512, 2048, 4096      # (1024: retired, see include/sodt_hip.h)
 STATS_REPL = 16      # SODT_STATS_REPL: replicas of the [2][N] f64 BatchNorm statistics buffer
 
 
@@ -52,8 +52,7 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("flags", C.c_int),
                 ("oscatter", C.c_int), ("omul", C.c_int), ("ody", C.c_int), ("odx", C.c_int),
                 ("OH", C.c_int), ("OW", C.c_int),
-                ("det_na", C.c_int), ("det_no", C.c_int), ("det_hw", C.c_int),
-                ("ln_dgamma", C.c_void_p), ("ln_dbeta", C.c_void_p)]
+                ("det_na", C.c_int), ("det_no", C.c_int), ("det_hw", C.c_int)]
 
 
 class GemmTnArgs(C.Structure):

@@ -16,8 +16,6 @@
 #include "gemm_epi.h"
 
 bool sodt_nt3_eligible(const sodt_gemm_args* g);            // gemm3.hip: pipelined bf16 kernel for K >= 384
-bool sodt_nt3_ln_eligible(const sodt_gemm_args* g);         // gemm3.hip: the same with the LayerNorm backward as epilogue
-int sodt_nt3_ln_launch(const sodt_gemm_args* g, hipStream_t st);
 int sodt_nt3_launch(const sodt_gemm_args* g, hipStream_t st);
 int sodt_tn3_launch(const sodt_gemm_tn_args* g, hipStream_t st);   // gemm3.hip: pipelined bf16 weight-gradient kernel
 
@@ -1043,10 +1041,6 @@ extern "C" int sodt_gemm_nt(const sodt_gemm_args* g, int dtype, sodt_stream_t st
   if ((g->flags & SODT_EPI_AFFINE_SILU) && (!g->scale || !g->shift || ((((uintptr_t)g->scale) | ((uintptr_t)g->shift)) & 15))) return SODT_EINVAL;
   if (g->oscatter && !g->a.spatial) return SODT_EINVAL;
   if ((g->flags & SODT_EPI_DGELU_RC) && !(dtype == SODT_BF16 && sodt_nt3_eligible(g))) return SODT_EINVAL;
-  if (g->flags & SODT_EPI_LNBWD) {           // no other kernel implements this epilogue
-    if (dtype != SODT_BF16 || !sodt_nt3_ln_eligible(g)) return SODT_EINVAL;
-    return sodt_nt3_ln_launch(g, (hipStream_t)st);
-  }
   if (dtype == SODT_BF16 && (g_variant == 0 || g_variant == 3) && sodt_nt3_eligible(g)) return sodt_nt3_launch(g, (hipStream_t)st);
   // short contraction -> A-stationary kernel (row bytes a multiple of 128 so the XOR swizzle stays in-row)
   {

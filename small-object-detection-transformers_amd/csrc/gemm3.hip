@@ -501,238 +501,6 @@ int launch_nt3(const sodt_gemm_args* g, hipStream_t st) {
 
 
 // ---------------------------------------------------------------------------------
-// NT GEMM with the LayerNorm BACKWARD as its epilogue (SODT_EPI_LNBWD; N == 192, one plain K-segment):
-//
-//     dy = A[M][K] @ W[192][K]^T          (the gradient of a LayerNorm's OUTPUT: dqkv Wqkv, dh W1, du Wfc1 - backbone_vit.py:1089,1128)
-//     dx = [R +] rstd * (g - mean(g) - xhat * mean(g * xhat)),   g = dy * gamma,  xhat = (x - mean) * rstd
-//     dgamma += sum_m dy * xhat,   dbeta += sum_m dy
-//
-// dy never goes to HBM: the separate sodt_layernorm_bwd launch read dy, x and R and wrote dx (4 token rows) after the GEMM
-// had written dy (1 row); here the GEMM's epilogue reads x and R and writes dx - two rows of C elements less per LayerNorm.
-// Same LDS-DMA rings, barrier / vmcnt protocol and fragment images as gemm_nt3_kernel; what differs is the wave tiling: the 8
-// waves stack along M (32 rows x ALL 192 columns each), so a token row lives in ONE wave (its 192 columns on 4 lanes x 6 column
-// groups x 8 registers) and the two row sums are two v_permlane swaps - no LDS exchange, no extra barrier.  Column sums for
-// dgamma / dbeta: DPP reduction over the 16 rows of a strip, then one LDS float atomic per 32 columns into a per-workgroup
-// table that is flushed with global atomics once per workgroup.
-// x / R / statistics of a strip are ordinary loads at the start of that strip's epilogue.
-// ---------------------------------------------------------------------------------
-constexpr int LN_GAM = T3_SEGOFF;                    // f32 gamma[192] | dgamma[192] | dbeta[192]
-constexpr int LN_LDS = LN_GAM + 3 * 192 * 4;
-
-template <bool HAS_R>
-__global__ __launch_bounds__(512) void gemm_nt3_ln_kernel(const sodt_gemm_args g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int fi = lane & 15, fg = lane >> 4;
-  const uint32_t lbase = lds_addr(dsm);
-  const float* gamma = g.shift;
-  for (int i = tid; i < 192; i += 512) {
-    *(float*)(dsm + LN_GAM + 4 * i) = gamma[i];
-    *(float*)(dsm + LN_GAM + 768 + 4 * i) = 0.f;
-    *(float*)(dsm + LN_GAM + 1536 + 4 * i) = 0.f;
-  }
-  __syncthreads();
-
-  const int ntiles = (g.M + T3_BM - 1) / T3_BM;
-  const int G = gridDim.x;
-  const int lw = blockIdx.x;
-  const int nt_my = lw < ntiles ? (ntiles - lw + G - 1) / G : 0;
-  const int nk = g.K / T3_BK;
-  const int total = nt_my * nk;
-  if (total == 0) return;
-  const unsigned char* zero = (const unsigned char*)&g_zero16;
-  const unsigned char* Ab = (const unsigned char*)g.a.s[0].p;
-  const long lda = g.a.s[0].ld;
-
-  // ---- A issue: wave-instruction q covers tile rows 32 wid + 8 q .. + 7 (this wave's own rows), chunk swizzle as gemm_nt3_kernel
-  const int arow0 = 32 * wid + (lane >> 3);
-  const int acb0 = ((lane & 7) ^ ((lane >> 4) & 3)) << 4;
-  const int acb1 = ((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4;
-  int a_ord = 0, a_kt = 0;
-  auto issue_a = [&](int slot) {
-    const uint32_t dst = T3_AST * slot + wid * 4096;
-    const long m0 = (long)(lw + a_ord * G) * T3_BM;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const long m = m0 + arow0 + 8 * q;
-      const unsigned char* src = zero;
-      if (a_ord < nt_my && m < g.M) src = Ab + ((m * lda + (long)a_kt * T3_BK) << 1) + ((q & 1) ? acb1 : acb0);
-      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dsm + dst + q * 1024), 16, 0, 0);
-    }
-    if (a_ord < nt_my && ++a_kt == nk) { a_kt = 0; ++a_ord; }
-  };
-  // ---- W issue: rows 8 (3 wid + q) + (lane >> 3) of the 192, swizzle as gemm_nt3_kernel
-  int b_ord = 0, b_kt = 0;
-  int wrow[3], wcb[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int row = 8 * (3 * wid + q) + (lane >> 3);
-    const int f = ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
-    wrow[q] = row; wcb[q] = ((lane & 7) ^ f) << 4;
-  }
-  auto issue_b = [&](int slot) {
-    const uint32_t dst = T3_BOFF + T3_BST * slot + wid * 3072;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const unsigned char* src = zero;
-      if (b_ord < nt_my) src = (const unsigned char*)g.W + (((long)wrow[q] * g.ldw + (long)b_kt * T3_BK) << 1) + wcb[q];
-      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dsm + dst + q * 1024), 16, 0, 0);
-    }
-    if (b_ord < nt_my && ++b_kt == nk) { b_kt = 0; ++b_ord; }
-  };
-
-  // ---- fragment read addresses: A rows 32 wid + 16 u + fi; W rows 32 t + 8 (fi >> 2) + (fi & 3) (+ 4 for the odd fragment)
-  const int fA = (fi >> 1) & 7;
-  const int fW = ((fi >> 1) & 1) | (((fi >> 2) & 3) << 1);
-  const uint32_t aRd0 = lbase + (wid * 32 + fi) * 128 + ((fg ^ fA) << 4);
-  const uint32_t aRd1 = lbase + (wid * 32 + fi) * 128 + (((4 + fg) ^ fA) << 4);
-  const int wr_row = 8 * (fi >> 2) + (fi & 3);
-  const uint32_t wRd0 = lbase + T3_BOFF + wr_row * 128 + ((fg ^ fW) << 4);
-  const uint32_t wRd1 = lbase + T3_BOFF + wr_row * 128 + (((4 + fg) ^ fW) << 4);
-
-  f32x4 acc[2][6][2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int t = 0; t < 6; ++t) { acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-  issue_a(0);
-  issue_b(0);
-  issue_a(1);
-  int a_slot = 0, b_slot = 0, c_ord = 0, c_kt = 0;
-  // x / R / statistics of one 16-row strip (this lane's 6 x 8 columns of row fi): ordinary loads, waited for by the compiler.  Its
-  // wait is vmcnt(0), which also retires the next tile's first stages (in flight since the last K-steps): accepted here - the
-  // alternative, inline-asm loads behind a counted wait, is only safe in a kernel without register spills, and this epilogue's
-  // peak (96 accumulators + 50 operand registers + temporaries) does not leave that margin
-  uint4 px[6], pr[6];
-  float2 pst;
-  auto strip_loads = [&](int u) {
-    const long m0 = (long)(lw + c_ord * G) * T3_BM;
-    long m = m0 + wid * 32 + 16 * u + fi;
-    if (m >= g.M) m = g.M - 1;
-    const bf16* xr = (const bf16*)g.aux + m * g.ldaux + 8 * fg;
-    const bf16* rr = HAS_R ? (const bf16*)g.R + m * g.ldr + 8 * fg : nullptr;
-    pst = *(const float2*)(g.scale + 2 * m);
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-      px[t] = *(const uint4*)(xr + 32 * t);
-      if (HAS_R) pr[t] = *(const uint4*)(rr + 32 * t);
-    }
-  };
-
-  for (int s = 0; s < total; ++s) {
-    // everything but the newest A stage has landed; the (up to) 12 output stores of a tile that ended in the previous K-step
-    // may stay in flight as well (they are younger than the stages needed now)
-    if (c_kt == 0 && s > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (c_kt == nk - 1) strip_loads(0);               // strip 0's operands land under the tile's last K-step
-    issue_b(b_slot ^ 1);
-    issue_a(a_slot == 0 ? 2 : a_slot - 1);
-    const uint32_t ao = a_slot * T3_AST, bo = b_slot * T3_BST;
-#define LN_KB(ARD, WRD, T0)                                                           \
-    {                                                                                \
-      u32x4 fa0 = lds_rd128<0>(ARD + ao), fa1 = lds_rd128<2048>(ARD + ao);            \
-      u32x4 fw0 = lds_rd128<(T0) * 4096>(WRD + bo), fw1 = lds_rd128<(T0) * 4096 + 512>(WRD + bo);            \
-      u32x4 fw2 = lds_rd128<(T0) * 4096 + 4096>(WRD + bo), fw3 = lds_rd128<(T0) * 4096 + 4608>(WRD + bo);    \
-      u32x4 fw4 = lds_rd128<(T0) * 4096 + 8192>(WRD + bo), fw5 = lds_rd128<(T0) * 4096 + 8704>(WRD + bo);    \
-      T3_LGKM0();                                                                    \
-      mma_sw(acc[0][(T0)][0], fw0, fa0); mma_sw(acc[0][(T0)][1], fw1, fa0);          \
-      mma_sw(acc[0][(T0) + 1][0], fw2, fa0); mma_sw(acc[0][(T0) + 1][1], fw3, fa0);  \
-      mma_sw(acc[0][(T0) + 2][0], fw4, fa0); mma_sw(acc[0][(T0) + 2][1], fw5, fa0);  \
-      mma_sw(acc[1][(T0)][0], fw0, fa1); mma_sw(acc[1][(T0)][1], fw1, fa1);          \
-      mma_sw(acc[1][(T0) + 1][0], fw2, fa1); mma_sw(acc[1][(T0) + 1][1], fw3, fa1);  \
-      mma_sw(acc[1][(T0) + 2][0], fw4, fa1); mma_sw(acc[1][(T0) + 2][1], fw5, fa1);  \
-    }
-    LN_KB(aRd0, wRd0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    LN_KB(aRd0, wRd0, 3)
-    __builtin_amdgcn_sched_barrier(0);
-    LN_KB(aRd1, wRd1, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    LN_KB(aRd1, wRd1, 3)
-#undef LN_KB
-    a_slot = a_slot == 2 ? 0 : a_slot + 1;
-    b_slot ^= 1;
-    if (++c_kt == nk) {
-      // ---- epilogue: lane (fg, fi) holds, per (u, t), columns 32 t + 8 fg .. + 7 of row m0 + 32 wid + 16 u + fi
-      const long m0 = (long)(lw + c_ord * G) * T3_BM;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (u == 1) strip_loads(1);
-        const long m = m0 + wid * 32 + 16 * u + fi;
-        const float mu = pst.x, rstd = pst.y;
-        const float nmr = -mu * rstd;
-        // pass 1: the two row sums
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-          const f32x4 g0 = *(const f32x4*)(dsm + LN_GAM + 4 * (32 * t + 8 * fg)), g1 = *(const f32x4*)(dsm + LN_GAM + 4 * (32 * t + 8 * fg) + 16);
-          float x[8];
-          unpack<bf16>(px[t], x);
-          const float gm[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float gg = acc[u][t][j >> 2][j & 3] * gm[j];
-            s1 += gg;
-            s2 = fmaf(gg, fmaf(x[j], rstd, nmr), s2);
-          }
-          __builtin_amdgcn_sched_barrier(0);           // one column group at a time: the unrolled groups' temporaries must not overlap
-        }
-        {   // the row's 192 columns sit on lanes fi, fi + 16, fi + 32, fi + 48
-          auto a_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
-          s1 = __uint_as_float(a_[0]) + __uint_as_float(a_[1]);
-          auto b_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
-          s1 = __uint_as_float(b_[0]) + __uint_as_float(b_[1]);
-          auto c_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
-          s2 = __uint_as_float(c_[0]) + __uint_as_float(c_[1]);
-          auto d_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
-          s2 = __uint_as_float(d_[0]) + __uint_as_float(d_[1]);
-        }
-        const float ca = s1 * (1.0f / 192.0f), cb = s2 * (1.0f / 192.0f);
-        const bool rowok = m < g.M;
-        // pass 2: dx, and the column sums of this strip
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-          const f32x4 g0 = *(const f32x4*)(dsm + LN_GAM + 4 * (32 * t + 8 * fg)), g1 = *(const f32x4*)(dsm + LN_GAM + 4 * (32 * t + 8 * fg) + 16);
-          float x[8], o[8], r[8];
-          unpack<bf16>(px[t], x);
-          if (HAS_R) unpack<bf16>(pr[t], r);
-          const float gm[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-          float dgs = 0.f, dbs = 0.f;          // lane fi == j keeps the strip's column sum of column 32 t + 8 fg + j
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float dy = rowok ? acc[u][t][j >> 2][j & 3] : 0.f;
-            const float xh = fmaf(x[j], rstd, nmr);
-            const float gg = dy * gm[j];
-            o[j] = rstd * (gg - ca - xh * cb);
-            if (HAS_R) o[j] += r[j];
-            const float cg = group16_sum(dy * xh), cbb = group16_sum(dy);
-            dgs = fi == j ? cg : dgs;
-            dbs = fi == j ? cbb : dbs;
-          }
-          if (rowok) *(uint4*)((bf16*)g.C + m * g.ldc + 32 * t + 8 * fg) = pack<bf16>(o);
-          if (fi < 8) {
-            atomicAdd((float*)(dsm + LN_GAM + 768 + 4 * (32 * t + 8 * fg + fi)), dgs);
-            atomicAdd((float*)(dsm + LN_GAM + 1536 + 4 * (32 * t + 8 * fg + fi)), dbs);
-          }
-          acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      c_kt = 0; ++c_ord;
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int i = tid; i < 384; i += 512) {
-    const float v = *(const float*)(dsm + LN_GAM + 768 + 4 * i);
-    if (v != 0.f) atomicAdd(i < 192 ? g.ln_dgamma + i : g.ln_dbeta + (i - 192), v);
-  }
-}
-
-// ---------------------------------------------------------------------------------
 // Pipelined bf16 TN GEMM (weight gradients):  dW[N][K] += dY[M][N]^T @ X[M][K]  (+ dbias = column sums of dY).
 // Same machinery as the NT kernel above: LDS-DMA ring (5 stages of 32 rows, 4 in flight), one raw barrier per
 // stage, counted vmcnt, inline-asm fragment reads.  Both operands are contracted along their LDS ROWS, so the
@@ -1096,35 +864,6 @@ int launch_tn3(const sodt_gemm_tn_args* g, hipStream_t st) {
 }
 
 }  // namespace
-
-// the LayerNorm-backward-epilogue kernel (bf16): flags == SODT_EPI_LNBWD [| SODT_EPI_RESID]
-bool sodt_nt3_ln_eligible(const sodt_gemm_args* g) {
-  const int f = g->flags;
-  if (f != SODT_EPI_LNBWD && f != (SODT_EPI_LNBWD | SODT_EPI_RESID)) return false;
-  if (g->N != T3_BN || g->K % T3_BK || g->K < T3_BK || g->M < T3_BM) return false;
-  if (g->a.nseg != 1 || g->a.spatial || g->a.s[0].klen != g->K || (g->a.s[0].ld % 8) || g->oscatter || g->rmod > 0) return false;
-  if (!g->aux || (g->ldaux % 8) || !g->scale || !g->shift || !g->ln_dgamma || !g->ln_dbeta || (g->ldw % 8) || (g->ldc % 8)) return false;
-  if ((f & SODT_EPI_RESID) && (!g->R || (g->ldr % 8))) return false;
-  return true;
-}
-
-int sodt_nt3_ln_launch(const sodt_gemm_args* g, hipStream_t st) {
-  const bool has_r = (g->flags & SODT_EPI_RESID) != 0;
-  static bool attr_set[2] = {false, false};
-  const void* kern = has_r ? (const void*)gemm_nt3_ln_kernel<true> : (const void*)gemm_nt3_ln_kernel<false>;
-  if (!attr_set[has_r]) {
-    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS) != hipSuccess) {
-      (void)hipGetLastError();
-      return SODT_EINVAL;
-    }
-    attr_set[has_r] = true;
-  }
-  const long ntiles = (g->M + T3_BM - 1) / T3_BM;
-  const int grid = (int)(ntiles < 256 ? ntiles : 256);
-  if (has_r) hipLaunchKernelGGL(gemm_nt3_ln_kernel<true>, dim3(grid), dim3(512), LN_LDS, st, *g);
-  else hipLaunchKernelGGL(gemm_nt3_ln_kernel<false>, dim3(grid), dim3(512), LN_LDS, st, *g);
-  return hipGetLastError() == hipSuccess ? SODT_OK : SODT_EINVAL;
-}
 
 // eligibility of the pipelined kernel (bf16 only); the caller has validated pointers / alignment
 bool sodt_nt3_eligible(const sodt_gemm_args* g) {

@@ -180,10 +180,6 @@ class Engine:
         # d(x) = du W1 and no dW1 GEMM; widths above this run the three-GEMM form (the composition kernels are plain f32 loops)
         self.convmlp_fold_maxc = 384
         self.use_direct_conv3 = True   # the head's 3x3 Conv at 64 -> 64 channels on the direct kernels (csrc/conv3.hip) against the nine-segment GEMM
-        # LayerNorm backward as the epilogue of the GEMM that produces its input gradient (SODT_EPI_LNBWD): built and pinned
-        # (tests/test_kernels_gpu.py), but measured SLOWER than the two launches it replaces at the bench shapes (0.45 vs 0.34 ms
-        # at K = 576: profiles/r04_lnfold_ab.md), so the step does not use it
-        self.use_ln_fold = False
         # 64 MiB of f32 for the per-slice partial tiles of the bf16 weight-gradient GEMMs (largest need: 12.5 M floats)
         self._tn_scratch = torch.empty(16 << 20, dtype=torch.float32, device=self.dev)
         ops.set_tn_scratch(self._tn_scratch)
@@ -828,15 +824,13 @@ class Engine:
             ops.gemm_nt(segs, wT[pre + "mlp.conv1.weight"], du, M, Cc, 4 * Cc, spatial=(H, W))
             ops.gemm_tn(du, [SegSpec(xn2)], g[pre + "mlp.fc1.weight"], M, Cc, Cc, dbias=g[pre + "mlp.fc1.bias"])
             dln2 = (du, Cc)
-        # d(xn2) = dln2 @ fc1.weight and the LayerNorm-2 backward (+ the residual path's dY): ONE launch where a token row fits a
-        # 192-column tile (stage 1, bf16: SODT_EPI_LNBWD - d(xn2) never goes to HBM), otherwise the GEMM and sodt_layernorm_bwd
+        # d(xn2) = dln2 @ fc1.weight, then the LayerNorm-2 backward (+ the residual path's dY).  (Rounds 4-5 carried a GEMM with the
+        # LayerNorm backward as its epilogue for the 192-column case: slower than these two launches, removed in round 6 -
+        # profiles/r04_lnfold_ab.md)
         if dln2 is None:
             segs = [SegSpec(dc, Cc, 0, -dy, -dx, 1, 0, H, W) for (dy, dx) in TAPS2]
             ops.gemm_nt(segs, cm["weffT"], dxn, M, Cc, 4 * Cc, spatial=(H, W))
             ops.layernorm_bwd(dxn, xm, b[tag + ".st2"], p[pre + "norm2.weight"], dY, dxm, g[pre + "norm2.weight"], g[pre + "norm2.bias"], M, Cc)
-        elif self.use_ln_fold and ops.ln_bwd_fold_ok(M, Cc, dln2[1], plan.dt):
-            ops.gemm_nt([SegSpec(dln2[0])], wT[pre + "mlp.fc1.weight"], dxm, M, Cc, dln2[1], resid=dY,
-                        ln_bwd=(xm, b[tag + ".st2"], p[pre + "norm2.weight"], g[pre + "norm2.weight"], g[pre + "norm2.bias"]))
         else:
             ops.gemm_nt([SegSpec(dln2[0])], wT[pre + "mlp.fc1.weight"], dxn, M, Cc, dln2[1])
             ops.layernorm_bwd(dxn, xm, b[tag + ".st2"], p[pre + "norm2.weight"], dY, dxm, g[pre + "norm2.weight"], g[pre + "norm2.bias"], M, Cc)
@@ -859,12 +853,8 @@ class Engine:
                                 dbt, scratch, B, H, W, Cc, HEADS, ws, shift)
         ops.transpose_f32(dbt, g[pre + "attn.relative_position_bias_table"], HEADS, L2 * L2, accumulate=2)
         ops.gemm_tn(dqkv, [SegSpec(xn1)], g[pre + "attn.qkv.weight"], M, 3 * Cc, Cc, dbias=g[pre + "attn.qkv.bias"])
-        if self.use_ln_fold and ops.ln_bwd_fold_ok(M, Cc, 3 * Cc, plan.dt):        # d(xn1) = dqkv @ qkv.weight + LayerNorm-1 backward + dxm, one launch
-            ops.gemm_nt([SegSpec(dqkv)], wT[pre + "attn.qkv.weight"], dX, M, Cc, 3 * Cc, resid=dxm,
-                        ln_bwd=(x_in, b[tag + ".st1"], p[pre + "norm1.weight"], g[pre + "norm1.weight"], g[pre + "norm1.bias"]))
-        else:
-            ops.gemm_nt([SegSpec(dqkv)], wT[pre + "attn.qkv.weight"], dxn, M, Cc, 3 * Cc)
-            ops.layernorm_bwd(dxn, x_in, b[tag + ".st1"], p[pre + "norm1.weight"], dxm, dX, g[pre + "norm1.weight"], g[pre + "norm1.bias"], M, Cc)
+        ops.gemm_nt([SegSpec(dqkv)], wT[pre + "attn.qkv.weight"], dxn, M, Cc, 3 * Cc)
+        ops.layernorm_bwd(dxn, x_in, b[tag + ".st1"], p[pre + "norm1.weight"], dxm, dX, g[pre + "norm1.weight"], g[pre + "norm1.bias"], M, Cc)
 
     # ------------------------------------------------------------------ PatchMerging
     def _merge_fwd(self, plan, P, tag, x, B, H, W, Cc):

@@ -132,8 +132,7 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
             stats: Optional[torch.Tensor] = None, affine: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
             out_f32: bool = False, detect: Optional[Tuple[int, int, int]] = None,
             oscatter: Optional[Tuple[int, int, int, int, int]] = None, w_off: int = 0,
-            gelu_only: bool = False, dgelu_rc: bool = False, relu: bool = False, drelu_aux: Optional[torch.Tensor] = None, aux_off: int = 0,
-            ln_bwd: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> None:
+            gelu_only: bool = False, dgelu_rc: bool = False, relu: bool = False, drelu_aux: Optional[torch.Tensor] = None, aux_off: int = 0) -> None:
     """out[M][N] = epilogue(concat_k(segs) @ W[N][K]^T); see SODT_EPI_* in include/sodt_hip.h."""
     g = L.GemmArgs()
     _fill_aspec(g.a, segs, spatial)
@@ -184,20 +183,8 @@ def gemm_nt(segs: Sequence[SegSpec], W: torch.Tensor, out: torch.Tensor, M: int,
         flags |= L.EPI_DRELU
         g.aux = drelu_aux.data_ptr() + aux_off * drelu_aux.element_size()
         g.ldaux = drelu_aux.shape[-1]
-    if ln_bwd is not None:      # (x, stats, gamma, dgamma, dbeta): the product is d(LayerNorm output); out = [resid +] LN'(product)
-        x_ln, st_ln, gam, dgam, dbet = ln_bwd
-        flags |= L.EPI_LNBWD
-        g.aux, g.ldaux = x_ln.data_ptr(), x_ln.shape[-1]
-        g.scale, g.shift = st_ln.data_ptr(), gam.data_ptr()
-        g.ln_dgamma, g.ln_dbeta = dgam.data_ptr(), dbet.data_ptr()
     g.M, g.N, g.K, g.flags = M, N, K, flags
     _launch("sodt_gemm_nt", C.byref(g), dt_code(W))
-
-
-def ln_bwd_fold_ok(M: int, N: int, K: int, dtype: torch.dtype) -> bool:
-    """The LayerNorm backward can run as the epilogue of the GEMM that produces its input gradient (SODT_EPI_LNBWD, csrc/gemm3.hip):
-    bf16, a token row in one 192-column tile, whole 64-wide K-steps."""
-    return dtype == torch.bfloat16 and N == 192 and K % 64 == 0 and K >= 64 and M >= 256
 
 
 def mlp_recompute_ok(M: int, Cc: int, dtype: torch.dtype) -> bool:

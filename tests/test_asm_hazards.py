@@ -129,7 +129,6 @@ CASES = [
     # file, kernel-name substring, minimum number of instantiations, each must contain inline-asm loads
     ("gemm3", "gemm_nt3_kernel", 12),
     ("gemm3", "gemm_tn3_kernel", 4),
-    ("gemm3", "gemm_nt3_ln_kernel", 2),
     ("wmsa_hg", "wmsa_hg_kernel", 4),
     ("wmsa_block", "wmsa_block_kernel", 3),
     ("mlp", "mlp_fwd_kernel", 4),

@@ -484,47 +484,6 @@ def test_layernorm(ops, dev, dt, Cc):
     close(db, br.grad, dt, what="ln dbeta")
 
 
-@pytest.mark.parametrize("M,K,with_res", [(1000, 192, True), (4096, 576, True), (2500, 768, False), (70000, 576, True)])
-def test_gemm_with_layernorm_backward_epilogue(ops, dev, M, K, with_res):
-    """SODT_EPI_LNBWD (bf16, N = 192): dx = [R +] LN'(A W^T), dgamma / dbeta accumulated - the input-gradient GEMM of a
-    LayerNorm's consumer with the LayerNorm backward (backbone_vit.py:1089,1128) as its epilogue - against float64 autograd of
-    F.layer_norm fed with the float64 product.  M = 1000 / 2500: ragged last tile; 70000: several tiles per
-    persistent workgroup."""
-    dt, N = torch.bfloat16, 192
-    assert ops.ln_bwd_fold_ok(M, N, K, dt)
-    a = rnd((M, K), dev, dt, 1, 0.5)
-    w = rnd((N, K), dev, dt, 2, 1.0 / K ** 0.5)
-    x = rnd((M, N), dev, dt, 3) * 1.5 + 0.3
-    gam = rnd((N,), dev, torch.float32, 4) * 0.2 + 1
-    bet = rnd((N,), dev, torch.float32, 5) * 0.2
-    res = rnd((M, N), dev, dt, 6) if with_res else None
-    y = torch.zeros_like(x)
-    st = torch.zeros(M, 2, device=dev)
-    ops.layernorm_fwd(x, gam, bet, y, st, M, N)
-    dx = torch.full((M, N), 9.0, device=dev, dtype=dt)
-    dg, db = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
-    ops.gemm_nt([ops.SegSpec(a)], w, dx, M, N, K, resid=res, ln_bwd=(x, st, gam, dg, db))
-    # a second call accumulates dgamma / dbeta (and must give the same dx)
-    dx2 = torch.zeros_like(dx)
-    ops.gemm_nt([ops.SegSpec(a)], w, dx2, M, N, K, resid=res, ln_bwd=(x, st, gam, dg, db))
-    torch.cuda.synchronize()
-    dy = a.double() @ w.double().t()
-    xr = x.double().requires_grad_(True)
-    gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
-    F.layer_norm(xr, (N,), gr, br, 1e-5).backward(dy)
-    ref = xr.grad + (res.double() if with_res else 0.0)
-    close(dx, ref, dt, what="LN-epilogue dx")
-    assert torch.equal(dx, dx2)
-    close(dg, 2 * gr.grad, dt, what="LN-epilogue dgamma")
-    close(db, 2 * br.grad, dt, what="LN-epilogue dbeta")
-    # and against the two launches it replaces (same inputs; dy rounded to bf16 there)
-    dyb = torch.zeros(M, N, device=dev, dtype=dt)
-    ops.gemm_nt([ops.SegSpec(a)], w, dyb, M, N, K)
-    dx3, dg3, db3 = torch.zeros_like(dx), torch.zeros(N, device=dev), torch.zeros(N, device=dev)
-    ops.layernorm_bwd(dyb, x, st, gam, res, dx3, dg3, db3, M, N)
-    close(dx, dx3.double(), dt, what="LN-epilogue vs GEMM + layernorm_bwd")
-
-
 # ------------------------------------------------------------------ window attention
 def _attn_ref(qkv, table, B, H, W, Cc, heads, ws, shift):
     """fp64 torch statement of roll/partition/attention/unpartition/roll (oracle/ref_torch.py:window_attention)."""
