@@ -29,6 +29,9 @@ def run(M, N, K, mode, taps=0):
         tl = [(dy, dx) for dy in (0, 1) for dx in (0, 1)] if taps == 4 else [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
         segs = [ops.SegSpec(x, C, 0, dy, dx, 1, 0, H, H) for dy, dx in tl]
         kw["spatial"] = (H, H)
+    elif mode == "dgelu_rc":      # the Linear-GELU-Linear backward: A = [xn | dy], W = [W1 | W2^T], pre-activation recomputed in the first K half
+        segs = [ops.SegSpec(torch.randn(M, K // 2, device=dev).to(dt)), ops.SegSpec(torch.randn(M, K // 2, device=dev).to(dt))]
+        kw["bias"] = bias; kw["dgelu_rc"] = True
     else:
         segs = [ops.SegSpec(torch.randn(M, K, device=dev).to(dt))]
     if mode in ("bias", "gelu", "gelu2", "biasres"): kw["bias"] = bias
@@ -41,7 +44,7 @@ def run(M, N, K, mode, taps=0):
     return t
 
 
-shapes = [(524288, 768, 384, "gelu", 0), (524288, 192, 768, "plain", 4), (524288, 192, 768, "plain", 0), (524288, 192, 576, "plain", 0),
+shapes = [(524288, 768, 384, "dgelu_rc", 0), (131072, 1536, 768, "dgelu_rc", 0), (524288, 768, 384, "gelu", 0), (524288, 192, 768, "plain", 4), (524288, 192, 768, "plain", 0), (524288, 192, 576, "plain", 0),
           (524288, 192, 768, "biasres", 0), (524288, 192, 768, "dgelu", 0), (524288, 768, 192, "gelu2", 0), (524288, 192, 192, "plain", 0),
           (131072, 384, 1536, "plain", 0), (131072, 1536, 768, "gelu", 0), (131072, 1152, 384, "bias", 0), (131072, 384, 384, "biasres", 0),
           (32768, 3072, 1536, "gelu", 0), (32768, 768, 3072, "biasres", 0), (524288, 192, 1728, "plain", 9)]

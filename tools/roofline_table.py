@@ -113,6 +113,7 @@ def main():
     eng = model._get_engine(); plan = eng.plans[(B, S, torch.bfloat16, True)]
     groups = collections.OrderedDict()
     total = 0.0
+    tot_bytes = s1_bytes = s1_ms = 0.0
     for which, calls in (("fwd", plan.fwd_main), ("bwd", plan.bwd_main)):
         evs = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in range(len(calls))}
         acc = collections.defaultdict(float)
@@ -127,6 +128,10 @@ def main():
             g = groups.setdefault((name.replace("sodt_", ""), shape), [0, 0.0, 0.0, 0.0, set()])
             g[0] += 1; g[1] += acc[i]; g[2] += byt; g[3] += fl; g[4].add(tag.split(".")[0])
             total += acc[i]
+            # the byte budget (VERDICT r5 task 3): algorithmic bytes of the whole step and of the stage-1 blocks
+            tot_bytes += byt
+            if tag.startswith("stage1."):
+                s1_bytes += byt; s1_ms += acc[i]
     lines = [f"# Per-kernel roofline table, one training step, B={B} @{S}x{S} bf16 (tools/roofline_table.py)", "",
              f"Sum of the recorded launches: {total:.2f} ms per step (live launches - front end, Detect, optimizer, prep - are outside the "
              "recorded plans: ~1.5 ms).  HIP events on the launch stream, mean of 3 steps.  bytes / flops are ALGORITHMIC (each operand "
@@ -145,6 +150,13 @@ def main():
             break
     lines.append("")
     lines.append(f"The rows above cover {100 * cum / total:.0f} % of the recorded step time.")
+    t1 = B * (S // 4) ** 2
+    nblk = len(model.image_encoder.stage1)
+    lines.append("")
+    lines.append(f"**Byte budget** (tracked since round 6): {tot_bytes / 1e9:.1f} GB of algorithmic HBM traffic per step over the launches whose cost "
+                 f"model is in this tool ({tot_bytes / 1e9 / B:.1f} GB per image) = {tot_bytes / 5e12 * 1e3:.1f} ms at the practical 5 TB/s against {total:.1f} ms "
+                 f"measured ({tot_bytes / total / 1e9:.0f} GB/s average); stage 1: {s1_bytes / 1e9:.1f} GB in {s1_ms:.1f} ms = "
+                 f"**{s1_bytes / nblk / (t1 * 192 * ES):.0f} passes over a [{t1}][192] bf16 tensor per block**, forward + backward.")
     out = "\n".join(lines)
     print(out)
     if len(sys.argv) > 1:
