@@ -155,7 +155,7 @@ def main():
     lines.append("")
     lines.append(f"**Byte budget** (tracked since round 6): {tot_bytes / 1e9:.1f} GB of algorithmic HBM traffic per step over the launches whose cost "
                  f"model is in this tool ({tot_bytes / 1e9 / B:.1f} GB per image) = {tot_bytes / 5e12 * 1e3:.1f} ms at the practical 5 TB/s against {total:.1f} ms "
-                 f"measured ({tot_bytes / total / 1e9:.0f} GB/s average); stage 1: {s1_bytes / 1e9:.1f} GB in {s1_ms:.1f} ms = "
+                 f"measured ({tot_bytes / (total * 1e-3) / 1e9:.0f} GB/s average); stage 1: {s1_bytes / 1e9:.1f} GB in {s1_ms:.1f} ms = "
                  f"**{s1_bytes / nblk / (t1 * 192 * ES):.0f} passes over a [{t1}][192] bf16 tensor per block**, forward + backward.")
     out = "\n".join(lines)
     print(out)
