@@ -514,6 +514,35 @@ def sr_goldens(out):
     print("[pin] wrote sr.pt")
 
 
+def pad_block_goldens(ref_vit, out):
+    """SwinTransformerBlock at resolutions that are NOT a multiple of the window (backbone_vit.py:619-643: zero padding after norm1,
+    cropped after the attention): unshifted / linear MLP and shifted / conv MLP.  Pins the oracle's padded window_partition; the
+    engine runs the unshifted case (stage 3 at S = 640, 768, ...), tests/test_pad_gpu.py."""
+    g = {}
+    for tag, kw, (H, W) in (
+        ("pad_lin", dict(dim=24, num_heads=12, window_size=8, shift_size=0, linear_mlp=True), (12, 20)),
+        ("pad_conv_shift", dict(dim=24, num_heads=12, window_size=8, shift_size=2, linear_mlp=False), (12, 12)),
+    ):
+        blk = ref_vit.SwinTransformerBlock(input_resolution=(H, W), **kw)
+        sd = tiny_sd(blk, 7)
+        x = R._hash01(tag, 2 * H * W * 24).view(2, H * W, 24).float().requires_grad_(True)
+        y = blk(x)
+        gw = R._hash01(tag + "g", y.numel()).view(y.shape).float()
+        (y * gw).sum().backward()
+        grads = {k: p.grad.clone() for k, p in blk.named_parameters()}
+        osd = {"b." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xo = x.detach().clone().requires_grad_(True)
+        yo = R.swin_block(osd, "b.", xo, H, W, kw["window_size"], kw["shift_size"], kw["linear_mlp"])
+        (yo * gw).sum().backward()
+        d = maxdiff(y, yo)
+        dg = max(maxdiff(grads[k], osd["b." + k].grad) for k in grads)
+        dx = maxdiff(x.grad, xo.grad)
+        print(f"[pin] {tag}: fwd {d:.2e} dparam {dg:.2e} dx {dx:.2e}")
+        assert d < 1e-5 and dg < 1e-4 and dx < 1e-5, tag
+        g[tag] = dict(cfg=dict(H=H, W=W, **kw), sd=sd, x=x.detach(), y=y.detach(), dx=x.grad.clone(), grads=grads)
+    torch.save(g, os.path.join(out, "pad_block.pt"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -523,12 +552,16 @@ def main():
     ap.add_argument("--only-spp", action="store_true")
     ap.add_argument("--only-spp-head", action="store_true")
     ap.add_argument("--only-sr", action="store_true")
+    ap.add_argument("--only-pad", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
     ref_model, ref_vit, ref_common = import_reference()
     if a.only_loss:
         loss_goldens(GOLD)
+        return
+    if a.only_pad:
+        pad_block_goldens(ref_vit, GOLD)
         return
     if a.only_autocast:
         autocast_goldens(ref_model, GOLD)
@@ -547,6 +580,7 @@ def main():
     if a.only_nms:
         return
     per_module_goldens(ref_vit, ref_common, GOLD)
+    pad_block_goldens(ref_vit, GOLD)
     spp_goldens(ref_common, GOLD)
     sr_goldens(GOLD)
     if not a.skip_full:

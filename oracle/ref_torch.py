@@ -51,18 +51,24 @@ DET_STRIDE = 4.0                    # basics/models/model.py:130
 # helpers
 # ----------------------------------------------------------------------------
 def window_partition(x: Tensor, ws: int) -> Tensor:
-    """backbone_vit.py:619-643 (padding never triggers at our sizes; asserted)."""
+    """backbone_vit.py:619-643: zero padding at the bottom / right when H or W is not a multiple of the window (the reference
+    pads AFTER norm1, so a pad token enters the attention as the qkv bias; pinned by tests/golden/pad_block.pt)."""
     B, H, W, C = x.shape
-    assert H % ws == 0 and W % ws == 0
-    x = x.view(B, H // ws, ws, W // ws, ws, C)
+    ph, pw = (-H) % ws, (-W) % ws
+    if ph or pw:
+        x = F.pad(x, (0, 0, 0, pw, 0, ph))
+    Hp, Wp = H + ph, W + pw
+    x = x.view(B, Hp // ws, ws, Wp // ws, ws, C)
     return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws, ws, C)
 
 
 def window_unpartition(w: Tensor, ws: int, H: int, W: int) -> Tensor:
-    """backbone_vit.py:646-672."""
-    B = w.shape[0] // ((H // ws) * (W // ws))
-    x = w.view(B, H // ws, W // ws, ws, ws, -1)
-    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
+    """backbone_vit.py:646-672 (the padding of window_partition is cropped away)."""
+    Hp, Wp = H + (-H) % ws, W + (-W) % ws
+    B = w.shape[0] // ((Hp // ws) * (Wp // ws))
+    x = w.view(B, Hp // ws, Wp // ws, ws, ws, -1)
+    x = x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, Hp, Wp, -1)
+    return x[:, :H, :W, :].contiguous() if (Hp > H or Wp > W) else x
 
 
 def shift_mask(H: int, W: int, ws: int, shift: int, dtype=torch.float32) -> Tensor:

@@ -713,6 +713,17 @@ class Engine:
         ao = plan.buf(tag + ".ao", (M, Cc))
         wpk = P["wmsa"].get(pre) if (ws == 8 and H % 8 == 0 and W % 8 == 0) else None
         fused = wpk is not None
+        # Resolution not a multiple of the window: the reference zero-pads AFTER norm1 and crops after the attention
+        # (backbone_vit.py:619-672, window_partition / window_unpartition), so a pad token enters the attention as the qkv BIAS.
+        # Unshifted blocks (stage 3 at S = 640, 768, ...: 40 x 40, 48 x 48 tokens against the 32-token window) run here through the
+        # spatial K-segments: the QKV GEMM writes the padded grid (rows outside read zeros), the attention runs on it, the
+        # projection reads it back cropped.  Shifted blocks would also need the reference's mask of the UNPADDED grid: not built.
+        Hp, Wp = H + (-H) % ws, W + (-W) % ws
+        padded = (Hp, Wp) != (H, W)
+        if padded and shift > 0:
+            raise NotImplementedError(f"{tag}: {H}x{W} tokens are not a multiple of the {ws}-token window of a SHIFTED block (the "
+                                      "reference's zero padding, backbone_vit.py:619-643, is built for unshifted blocks only): choose "
+                                      "an input size S that is a multiple of 64")
         if fused:
             # LN1 + QKV + window attention + proj + residual + LN2 in ONE launch (csrc/wmsa_hg.hip / wmsa_block.hip); training also
             # writes what the backward needs: xn1, the attention output, the LayerNorm statistics and the window-major
@@ -724,6 +735,18 @@ class Engine:
                 ops.wmsa_block_fwd(x_in, wpk, xm, xn2, st1, st2, xn1, qkvw, lsew, ao, B, H, W, Cc, HEADS, ws, shift)
             else:
                 ops.wmsa_block_fwd(x_in, wpk, xm, xn2, None, None, None, None, None, None, B, H, W, Cc, HEADS, ws, shift)
+        elif padded:
+            Mp = B * Hp * Wp
+            ops.layernorm_fwd(x_in, p[pre + "norm1.weight"], p[pre + "norm1.bias"], xn1, st1, M, Cc)
+            qkv = plan.buf(tag + ".qkv", (Mp, 3 * Cc))
+            ops.gemm_nt([SegSpec(xn1, Cc, 0, 0, 0, 1, 0, H, W)], w[pre + "attn.qkv.weight"], qkv, Mp, 3 * Cc, Cc, spatial=(Hp, Wp),
+                        bias=p[pre + "attn.qkv.bias"])
+            lse = plan.buf(tag + ".lse", (Mp, HEADS), torch.float32)
+            aop = plan.buf(tag + ".aop", (Mp, Cc))
+            ops.window_attn_fwd(qkv, P["bias_t"][pre + "attn.relative_position_bias_table"], aop, lse, B, Hp, Wp, Cc, HEADS, ws, 0)
+            ops.gemm_nt([SegSpec(aop, Cc, 0, 0, 0, 1, 0, Hp, Wp)], w[pre + "attn.proj.weight"], xm, M, Cc, Cc, spatial=(H, W),
+                        bias=p[pre + "attn.proj.bias"], resid=x_in)
+            ops.layernorm_fwd(xm, p[pre + "norm2.weight"], p[pre + "norm2.bias"], xn2, st2, M, Cc)
         else:
             ops.layernorm_fwd(x_in, p[pre + "norm1.weight"], p[pre + "norm1.bias"], xn1, st1, M, Cc)
             qkv = plan.buf(tag + ".qkv", (M, 3 * Cc))
@@ -769,7 +792,7 @@ class Engine:
             ops.gemm_nt(segs, w[pre + "mlp.conv1.weight"], cp, M, Cc, 4 * Cc, spatial=(H, W), bias=p[pre + "mlp.conv1.bias"],
                         gelu_out=ca)
             ops.gemm_nt([SegSpec(ca)], w[pre + "mlp.fc2.weight"], xo, M, Cc, Cc, bias=p[pre + "mlp.fc2.bias"], resid=xm)
-        plan.saved[tag] = dict(x_in=x_in, geo=(B, H, W, Cc, ws, shift), fused=fused, wpk=wpk)
+        plan.saved[tag] = dict(x_in=x_in, geo=(B, H, W, Cc, ws, shift), fused=fused, wpk=wpk, pad=(Hp, Wp) if padded else None)
         return xo
 
     def _block_bwd(self, plan, P, tag, blk, dY, dX):
@@ -835,6 +858,9 @@ class Engine:
             ops.gemm_nt([SegSpec(dln2[0])], wT[pre + "mlp.fc1.weight"], dxn, M, Cc, dln2[1])
             ops.layernorm_bwd(dxn, xm, b[tag + ".st2"], p[pre + "norm2.weight"], dY, dxm, g[pre + "norm2.weight"], g[pre + "norm2.bias"], M, Cc)
         # attention
+        if sv.get("pad"):
+            self._padded_attn_bwd(plan, P, tag, pre, sv, dxm, dxn, dX)
+            return
         ops.gemm_tn(dxm, [SegSpec(ao)], g[pre + "attn.proj.weight"], M, Cc, Cc, dbias=g[pre + "attn.proj.bias"])
         dao = dxn
         ops.gemm_nt([SegSpec(dxm)], wT[pre + "attn.proj.weight"], dao, M, Cc, Cc)
@@ -855,6 +881,33 @@ class Engine:
         ops.gemm_tn(dqkv, [SegSpec(xn1)], g[pre + "attn.qkv.weight"], M, 3 * Cc, Cc, dbias=g[pre + "attn.qkv.bias"])
         ops.gemm_nt([SegSpec(dqkv)], wT[pre + "attn.qkv.weight"], dxn, M, Cc, 3 * Cc)
         ops.layernorm_bwd(dxn, x_in, b[tag + ".st1"], p[pre + "norm1.weight"], dxm, dX, g[pre + "norm1.weight"], g[pre + "norm1.bias"], M, Cc)
+
+    def _padded_attn_bwd(self, plan, P, tag, pre, sv, dxm, dxn, dX):
+        """Attention half of the backward of an UNSHIFTED block whose resolution is not a multiple of its window (see _block_fwd): the
+        projection's input gradient lands on the padded grid (zeros outside: the crop's adjoint), the attention backward runs on it,
+        qkv.weight sees zero rows for the pad tokens while qkv.bias collects their gradient (their q / k / v ARE the bias), and the
+        input gradient is read back cropped."""
+        p, wT, g, b = self.params, P["wT"], self.g, plan.bufs
+        B, H, W, Cc, ws, _ = sv["geo"]
+        Hp, Wp = sv["pad"]
+        M, Mp = B * H * W, B * Hp * Wp
+        aop, qkv, lse = b[tag + ".aop"], b[tag + ".qkv"], b[tag + ".lse"]
+        ops.gemm_tn(dxm, [SegSpec(aop, Cc, 0, 0, 0, 1, 0, Hp, Wp)], g[pre + "attn.proj.weight"], M, Cc, Cc, spatial=(H, W),
+                    dbias=g[pre + "attn.proj.bias"])
+        daop = plan.buf(f"g.daop.{Cc}", (Mp, Cc))
+        ops.gemm_nt([SegSpec(dxm, Cc, 0, 0, 0, 1, 0, H, W)], wT[pre + "attn.proj.weight"], daop, Mp, Cc, Cc, spatial=(Hp, Wp))
+        dqkv = plan.buf(f"g.dqkvp.{Cc}", (Mp, 3 * Cc))
+        L2 = 2 * ws - 1
+        dbt = plan.buf(f"g.dbt.{L2}", (HEADS, L2 * L2), torch.float32, zero=True)
+        scratch = plan.buf(f"g.attn_scratchp.{Cc}", (Mp * (Cc + HEADS),), torch.float32, zero=True) if ws * ws > 64 else None
+        ops.window_attn_bwd(qkv, P["bias_t"][pre + "attn.relative_position_bias_table"], aop, daop, lse, dqkv, dbt, scratch,
+                            B, Hp, Wp, Cc, HEADS, ws, 0)
+        ops.transpose_f32(dbt, g[pre + "attn.relative_position_bias_table"], HEADS, L2 * L2, accumulate=2)
+        ops.gemm_tn(dqkv, [SegSpec(b[tag + ".xn1"], Cc, 0, 0, 0, 1, 0, H, W)], g[pre + "attn.qkv.weight"], Mp, 3 * Cc, Cc,
+                    spatial=(Hp, Wp), dbias=g[pre + "attn.qkv.bias"])
+        ops.gemm_nt([SegSpec(dqkv, 3 * Cc, 0, 0, 0, 1, 0, Hp, Wp)], wT[pre + "attn.qkv.weight"], dxn, M, Cc, 3 * Cc, spatial=(H, W))
+        ops.layernorm_bwd(dxn, sv["x_in"], b[tag + ".st1"], p[pre + "norm1.weight"], dxm, dX, g[pre + "norm1.weight"],
+                          g[pre + "norm1.bias"], M, Cc)
 
     # ------------------------------------------------------------------ PatchMerging
     def _merge_fwd(self, plan, P, tag, x, B, H, W, Cc):

@@ -59,7 +59,11 @@ def _shift_mask(H: int, W: int, ws: int, shift: int) -> torch.Tensor:   # backbo
         for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
             img[:, hs, wsl, :] = cnt
             cnt += 1
-    mw = img.view(1, H // ws, ws, W // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws)
+    ph, pw = (-H) % ws, (-W) % ws             # window_partition's zero padding (backbone_vit.py:632-639): pad tokens get region id 0
+    if ph or pw:
+        img = torch.nn.functional.pad(img, (0, 0, 0, pw, 0, ph))
+    Hp, Wp = H + ph, W + pw
+    mw = img.view(1, Hp // ws, ws, Wp // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws)
     m = mw.unsqueeze(1) - mw.unsqueeze(2)
     return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
 

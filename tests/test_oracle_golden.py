@@ -32,6 +32,23 @@ def test_swin_block(per_module, tag):
         assert md(sd["b." + k].grad, v) < 1e-4, k
 
 
+@pytest.mark.parametrize("tag", ["pad_lin", "pad_conv_shift"])
+def test_swin_block_with_window_padding(tag):
+    """Resolutions that are not a multiple of the window: the reference zero-pads AFTER norm1 and crops after the attention
+    (backbone_vit.py:619-672); shifted blocks roll the unpadded grid first and mask with the region ids of the unpadded grid.
+    tests/golden/pad_block.pt comes from the reference's own SwinTransformerBlock (oracle/gen_golden.py --only-pad)."""
+    g = torch.load(os.path.join(GOLD, "pad_block.pt"))[tag]
+    c = g["cfg"]
+    sd = {"b." + k: v.clone().requires_grad_(True) for k, v in g["sd"].items()}
+    x = g["x"].clone().requires_grad_(True)
+    y = R.swin_block(sd, "b.", x, c["H"], c["W"], c["window_size"], c["shift_size"], c["linear_mlp"])
+    assert md(y, g["y"]) < 1e-5
+    (y * R._hash01(tag + "g", y.numel()).view(y.shape).float()).sum().backward()
+    assert md(x.grad, g["dx"]) < 1e-5
+    for k, v in g["grads"].items():
+        assert md(sd["b." + k].grad, v) < 1e-4, k
+
+
 def test_patch_merging_and_embed(per_module):
     g = per_module["pmerge"]
     y = R.patch_merging({"p." + k: v for k, v in g["sd"].items()}, "p.", g["x"], g["H"], g["W"])
