@@ -75,3 +75,22 @@ def test_shifted_block_with_padding_is_refused(dev):
     x_rgb, x_ir = R.synthetic_inputs(1, 96, seed=6)
     with pytest.raises(NotImplementedError, match="SHIFTED block"):
         model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
+
+
+@pytest.mark.parametrize("S", [320, 576, 704, 896])
+def test_forward_at_sizes_that_are_multiples_of_64(dev, S):
+    """Every S = 64 k runs: stage 3 is clamped to one window (S <= 512: 20 x 20 tokens at 320), padded (576: 36 -> 64, 704: 44 -> 64,
+    896: 56 -> 64) or exact (1024); f32 training-mode logits and the three encoder features against the oracle."""
+    from oracle import ref_torch as R
+    model, sd = build(dev, S)
+    model.compute_dtype = torch.float32
+    model.train()
+    x_rgb, x_ir = R.synthetic_inputs(1, S, seed=S)
+    with torch.no_grad():
+        pred, y = model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
+        opred, oy = R.model_forward({k: v.clone() for k, v in sd.items()}, x_rgb, x_ir, True, {})
+    e, s = rel(pred[0], opred[0])
+    assert e <= 1e-3, f"S={S}: logits {e:.3e} (scale {s:.2f})"
+    for i in range(3):
+        e, s = rel(y[i], oy[i])
+        assert e <= 1e-3 * max(1.0, s), f"S={S}: encoder feature {i}: {e:.3e} / {s:.2f}"
