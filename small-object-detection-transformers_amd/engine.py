@@ -692,6 +692,10 @@ class Engine:
         ws, shift = blk.window_size, blk.shift_size
         if min(H, W) <= ws:
             ws, shift = min(H, W), 0
+            if ws < 8 or 64 % ws:
+                raise NotImplementedError(f"a {H}x{W}-token stage is ONE {ws}x{ws} window (backbone_vit.py:1042-1045: no partition below "
+                                          "the window size); the attention kernels walk 64-token tiles of whole window rows (window "
+                                          "side 8, 16 or 32): below S = 576 use S = 128, 256 or 512 (from 576 on every multiple of 64 runs)")
         L2 = 2 * ws - 1
         if blk.attn.relative_position_bias_table.shape[0] != L2 * L2:
             raise ValueError(f"input resolution gives a {ws}x{ws} window but the model was built with a "

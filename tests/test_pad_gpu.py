@@ -77,10 +77,11 @@ def test_shifted_block_with_padding_is_refused(dev):
         model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
 
 
-@pytest.mark.parametrize("S", [320, 576, 704, 896])
+@pytest.mark.parametrize("S", [256, 576, 704, 896])
 def test_forward_at_sizes_that_are_multiples_of_64(dev, S):
-    """Every S = 64 k runs: stage 3 is clamped to one window (S <= 512: 20 x 20 tokens at 320), padded (576: 36 -> 64, 704: 44 -> 64,
-    896: 56 -> 64) or exact (1024); f32 training-mode logits and the three encoder features against the oracle."""
+    """From S = 576 on every multiple of 64 runs: stage 3 is padded (576: 36 -> 64 tokens per side, 704: 44 -> 64, 896: 56 -> 64) or
+    exact (1024).  Below, stage 3 is ONE clamped window of S / 16 tokens per side, which the attention kernels take when 64-token
+    tiles cover whole window rows: S = 128, 256, 512.  f32 training-mode logits and the three encoder features against the oracle."""
     from oracle import ref_torch as R
     model, sd = build(dev, S)
     model.compute_dtype = torch.float32
@@ -94,3 +95,14 @@ def test_forward_at_sizes_that_are_multiples_of_64(dev, S):
     for i in range(3):
         e, s = rel(y[i], oy[i])
         assert e <= 1e-3 * max(1.0, s), f"S={S}: encoder feature {i}: {e:.3e} / {s:.2f}"
+
+
+def test_single_window_stage_of_an_odd_size_is_refused_by_name(dev):
+    """S = 320: stage 3 is one 20 x 20 window - 64-token tiles do not cover whole rows of it."""
+    from oracle import ref_torch as R
+    model, _ = build(dev, 320)
+    model.compute_dtype = torch.float32
+    model.train()
+    x_rgb, x_ir = R.synthetic_inputs(1, 320, seed=7)
+    with pytest.raises(NotImplementedError, match="ONE 20x20 window"):
+        model(x_rgb.to(dev), x_ir.to(dev), "RGB+IR")
