@@ -153,3 +153,29 @@ def test_host_helpers(ops):
     assert ops.tn_splits(512, 192, 768, True) == ops.tn_splits(512, 192, 768)      # short M keeps the f32-path rule
     s = ops.SegSpec(torch.zeros(4, 96), 32, 64)
     assert (s.ld, s.klen, s.coff) == (96, 32, 64)
+
+
+def test_sr_direct_conv_bias_operand(pkg):
+    """advisor r5: the direct 64 -> <= 8 convolution reads 8 bias floats; at cout == 8 there is no zero-padded copy (np_ == cout) and
+    the parameter itself must be passed (a None there silently dropped the bias), at cout < 8 the padded copy, without a bias None."""
+    import importlib
+    import types
+    sr = importlib.import_module("small-object-detection-transformers_amd.sr")
+    b8, pad = torch.arange(8.0), torch.zeros(8)
+    assert sr.SRBranch._bias8(types.SimpleNamespace(bias=b8, bias_pad=None)) is b8
+    assert sr.SRBranch._bias8(types.SimpleNamespace(bias=torch.arange(4.0), bias_pad=pad)) is pad
+    assert sr.SRBranch._bias8(types.SimpleNamespace(bias=None, bias_pad=None)) is None
+
+
+def test_engine_names_the_input_sizes_it_refuses(M):
+    """Window padding (round 6): the geometry helper must refuse, by name, the single-window stages whose rows 64-token tiles do not
+    cover; it accepts 8 / 16 / 32-token windows and leaves larger grids to the padded path."""
+    import importlib
+    import types
+    E = importlib.import_module("small-object-detection-transformers_amd.engine")
+    tab = lambda ws: types.SimpleNamespace(relative_position_bias_table=torch.zeros((2 * ws - 1) ** 2, 12), window_size=(ws, ws))
+    geo = E.Engine._block_geo
+    assert geo(None, types.SimpleNamespace(window_size=32, shift_size=0, attn=tab(16)), 16, 16) == (16, 0)     # clamped to one window
+    assert geo(None, types.SimpleNamespace(window_size=32, shift_size=0, attn=tab(32)), 40, 40) == (32, 0)     # padded by the caller
+    with pytest.raises(NotImplementedError, match="ONE 20x20 window"):
+        geo(None, types.SimpleNamespace(window_size=32, shift_size=0, attn=tab(20)), 20, 20)
